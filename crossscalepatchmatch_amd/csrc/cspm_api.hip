@@ -1,0 +1,827 @@
+// cspm_api.hip -- host side of libcspm_hip.so: the C ABI declared in include/cspm.h.
+// Owns device memory, builds the plane-cost object (PreSSPC / PreCSPC) on the device and drives the
+// PatchMatch kernels.  No CPU fallback anywhere: without a usable gfx950 device every call fails.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cspm_kernels.h"
+
+using namespace cspm;
+
+namespace {
+
+std::string g_create_error;
+
+struct TimingRec {
+  int kclass;
+  hipEvent_t a, b;
+  long long evals;
+};
+
+}  // namespace
+
+struct cspm_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  // images
+  int W = 0, H = 0;
+  uint32_t *img0[2] = {nullptr, nullptr};
+  // cost object
+  bool cost_alloc = false, cost_ready = false;
+  Cost cost{};
+  int max_dis = 0, wnd = 0;
+  double scale_wgt[CSPM_MAX_LEVELS] = {0};
+  double host_max_cost[2 * CSPM_MAX_LEVELS] = {0};
+  std::vector<void *> cost_allocs;
+  double *d_lut = nullptr, *d_maxcost = nullptr;
+  unsigned long long *d_maxkeys = nullptr;
+  // plane field
+  bool field_alloc = false;
+  double *field_mem = nullptr;
+  Field f[2]{};
+  ViewCand vc{nullptr, nullptr, nullptr};
+  uint8_t *d_dis[2] = {nullptr, nullptr};
+  // timing
+  bool timing = false;
+  std::vector<TimingRec> recs;
+  std::vector<hipEvent_t> pool;
+  double acc_ms[CSPM_K_COUNT] = {0};
+  long long acc_launch[CSPM_K_COUNT] = {0}, acc_evals[CSPM_K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(cspm_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                            \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return fail(ctx, CSPM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+template <class T>
+int dalloc(cspm_ctx *c, T **p, size_t n, std::vector<void *> *track) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, n * sizeof(T) ? n * sizeof(T) : sizeof(T));
+  if (e != hipSuccess) return fail(c, CSPM_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  *p = (T *)q;
+  if (track) track->push_back(q);
+  return CSPM_OK;
+}
+
+hipEvent_t get_event(cspm_ctx *c) {
+  if (!c->pool.empty()) {
+    hipEvent_t e = c->pool.back();
+    c->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// bracket a launch with events when timing is on
+struct Timed {
+  cspm_ctx *c;
+  TimingRec r{};
+  bool on;
+  Timed(cspm_ctx *ctx, int kclass, long long evals) : c(ctx), on(ctx->timing) {
+    if (!on) return;
+    r.kclass = kclass;
+    r.evals = evals;
+    r.a = get_event(c);
+    r.b = get_event(c);
+    (void)hipEventRecord(r.a, c->stream);
+  }
+  ~Timed() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, c->stream);
+    c->recs.push_back(r);
+  }
+};
+
+int drain_timing(cspm_ctx *c) {
+  if (c->recs.empty()) return CSPM_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto &r : c->recs) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    c->acc_ms[r.kclass] += ms;
+    c->acc_launch[r.kclass] += 1;
+    c->acc_evals[r.kclass] += r.evals;
+    c->pool.push_back(r.a);
+    c->pool.push_back(r.b);
+  }
+  c->recs.clear();
+  return CSPM_OK;
+}
+
+inline unsigned eval_grid(long long items) {
+  long long nb = (items + (kEvalBlock / kWave) - 1) / (kEvalBlock / kWave);
+  nb = (nb + 7) / 8 * 8;
+  if (nb < 8) nb = 8;
+  return (unsigned)nb;
+}
+inline unsigned ew_grid(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+
+void free_cost(cspm_ctx *c) {
+  for (void *p : c->cost_allocs) (void)hipFree(p);
+  c->cost_allocs.clear();
+  c->cost_alloc = c->cost_ready = false;
+  memset(&c->cost, 0, sizeof c->cost);
+}
+void free_field(cspm_ctx *c) {
+  if (c->field_mem) (void)hipFree(c->field_mem);
+  if (c->vc.cost) (void)hipFree(c->vc.cost);
+  if (c->vc.c) (void)hipFree(c->vc.c);
+  if (c->vc.cx) (void)hipFree(c->vc.cx);
+  for (int v = 0; v < 2; ++v) {
+    if (c->d_dis[v]) (void)hipFree(c->d_dis[v]);
+    c->d_dis[v] = nullptr;
+  }
+  c->field_mem = nullptr;
+  c->vc = ViewCand{nullptr, nullptr, nullptr};
+  c->field_alloc = false;
+}
+void free_images(cspm_ctx *c) {
+  for (int v = 0; v < 2; ++v) {
+    if (c->img0[v]) (void)hipFree(c->img0[v]);
+    c->img0[v] = nullptr;
+  }
+  c->W = c->H = 0;
+}
+
+// pre_cs_pc.cc:86-109: scale_wgt[s] = inv(tridiag(lambda))(0,s); Mat::inv() = LU with partial pivoting
+// and reciprocal pivots (OpenCV 2.4 LUImpl), identity right-hand side.
+int scale_weights(int S, double lambda, double *w) {
+  if (S < 1 || S > CSPM_MAX_LEVELS) return -1;
+  double A[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS] = {{0}}, B[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS] = {{0}};
+  for (int s = 0; s < S; ++s) {
+    B[s][s] = 1.0;
+    if (S == 1) { A[0][0] = 1 + lambda; break; }
+    if (s == 0) { A[s][s] = 1 + lambda; A[s][s + 1] = -lambda; }
+    else if (s == S - 1) { A[s][s] = 1 + lambda; A[s][s - 1] = -lambda; }
+    else { A[s][s] = 1 + 2 * lambda; A[s][s - 1] = -lambda; A[s][s + 1] = -lambda; }
+  }
+  const double eps = DBL_EPSILON * 100;
+  for (int i = 0; i < S; ++i) {
+    int k = i;
+    for (int j = i + 1; j < S; ++j)
+      if (std::fabs(A[j][i]) > std::fabs(A[k][i])) k = j;
+    if (std::fabs(A[k][i]) < eps) return -2;
+    if (k != i) {
+      for (int j = i; j < S; ++j) std::swap(A[i][j], A[k][j]);
+      for (int j = 0; j < S; ++j) std::swap(B[i][j], B[k][j]);
+    }
+    const double d = -1 / A[i][i];
+    for (int j = i + 1; j < S; ++j) {
+      const double alpha = A[j][i] * d;
+      for (int q = i + 1; q < S; ++q) A[j][q] += alpha * A[i][q];
+      for (int q = 0; q < S; ++q) B[j][q] += alpha * B[i][q];
+    }
+    A[i][i] = -d;
+  }
+  for (int i = S - 1; i >= 0; --i)
+    for (int j = 0; j < S; ++j) {
+      double s = B[i][j];
+      for (int q = i + 1; q < S; ++q) s -= A[i][q] * B[q][j];
+      B[i][j] = s * A[i][i];
+    }
+  for (int s = 0; s < S; ++s) w[s] = B[0][s];
+  return 0;
+}
+
+// allocate pyramid images + volumes, fill Cost (everything except volume contents / max_cost)
+int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+  if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
+  if (max_dis < 1 || wnd_size < 1 || wnd_size > 127 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
+    return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
+  free_cost(c);
+  Cost &cd = c->cost;
+  cd.cs = scale_num > 0;
+  cd.levels = cd.cs ? scale_num : 1;
+  cd.half = wnd_size / 2;
+  cd.n = 2 * cd.half + 1;
+  cd.T = cd.n * cd.n;
+  cd.groups = (cd.T + kWave - 1) / kWave;
+  c->max_dis = max_dis;
+  c->wnd = wnd_size;
+  int rc;
+  // pre_cs_pc.cc:36-55
+  int W = c->W, H = c->H, D = max_dis;
+  for (int s = 0; s < cd.levels; ++s) {
+    if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
+    Level &L = cd.lv[s];
+    L.W = W; L.H = H; L.D = D;
+    for (int v = 0; v < 2; ++v) {
+      uint32_t *img;
+      double *vol;
+      if ((rc = dalloc(c, &img, (size_t)W * H, &c->cost_allocs))) return rc;
+      if ((rc = dalloc(c, &vol, (size_t)(D + 1) * W * H, &c->cost_allocs))) return rc;
+      L.img[v] = img;
+      L.vol[v] = vol;
+      if (s == 0) {
+        HIPCHK(c, hipMemcpyAsync(img, c->img0[v], sizeof(uint32_t) * (size_t)W * H, hipMemcpyDeviceToDevice, c->stream));
+      } else {
+        const Level &P = cd.lv[s - 1];
+        Timed t(c, CSPM_K_MISC, 0);
+        hipLaunchKernelGGL(k_pyrdown, dim3(ew_grid((long long)W * H)), dim3(256), 0, c->stream, P.img[v], P.W, P.H, img, W, H);
+      }
+    }
+  }
+  // scale weights (pre_cs_pc.cc:86-109) and exp LUT (pre_cs_pc.cc:111-114)
+  if (cd.cs) {
+    if (scale_weights(cd.levels, reg_lambda, c->scale_wgt)) return fail(c, CSPM_ERR_ARG, "singular regularisation matrix");
+  } else {
+    c->scale_wgt[0] = 1.0;
+  }
+  for (int s = 0; s < cd.levels; ++s) cd.lv[s].wgt = c->scale_wgt[s];
+  double lut[kLutSize];
+  for (int i = 0; i < kLutSize; ++i) lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
+  if ((rc = dalloc(c, &c->d_lut, kLutSize, &c->cost_allocs))) return rc;
+  if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
+  if ((rc = dalloc(c, &c->d_maxkeys, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // lut[] is a stack buffer
+  cd.lut = c->d_lut;
+  cd.max_cost = c->d_maxcost;
+  c->cost_alloc = true;
+  return CSPM_OK;
+}
+
+int finish_cost(cspm_ctx *c) {
+  Cost &cd = c->cost;
+  hipLaunchKernelGGL(k_keys_to_f64, dim3(1), dim3(64), 0, c->stream, c->d_maxkeys, c->d_maxcost, 2 * CSPM_MAX_LEVELS, -1.0);
+  HIPCHK(c, hipMemcpyAsync(c->host_max_cost, c->d_maxcost, sizeof c->host_max_cost, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cd.early_ok = 1;
+  for (int s = 0; s < cd.levels; ++s) {
+    if (!(c->scale_wgt[s] >= 0.0)) cd.early_ok = 0;
+    for (int v = 0; v < 2; ++v)
+      if (!(c->host_max_cost[v * CSPM_MAX_LEVELS + s] >= 0.0)) cd.early_ok = 0;
+  }
+  c->cost_ready = true;
+  return CSPM_OK;
+}
+
+int ensure_field(cspm_ctx *c) {
+  if (c->field_alloc) return CSPM_OK;
+  const size_t n = (size_t)c->W * c->H;
+  int rc;
+  if ((rc = dalloc(c, &c->field_mem, 14 * n, nullptr))) return rc;
+  for (int v = 0; v < 2; ++v) {
+    double *base = c->field_mem + (size_t)v * 7 * n;
+    c->f[v] = Field{base, base + n, base + 2 * n, base + 3 * n, base + 4 * n, base + 5 * n, base + 6 * n};
+  }
+  if ((rc = dalloc(c, &c->vc.cost, n, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->vc.c, n, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->vc.cx, n, nullptr))) return rc;
+  for (int v = 0; v < 2; ++v)
+    if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
+  c->field_alloc = true;
+  return CSPM_OK;
+}
+
+Pm make_pm(cspm_ctx *c, const cspm_pm_params *p) {
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.max_dis = c->max_dis;
+  pm.seed = p->seed;
+  pm.rng_row_shared = p->rng_mode == CSPM_RNG_ROW_SHARED;
+  pm.use_thresh = (p->early_exit && c->cost.early_ok) ? 1 : 0;
+  pm.f[0] = c->f[0];
+  pm.f[1] = c->f[1];
+  return pm;
+}
+
+const cspm_pm_params kDefaultParams = {12345ULL, CSPM_SCHED_REDBLACK, 1, 4, CSPM_RNG_PER_PIXEL, 1};
+
+int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
+  if (!c) return CSPM_ERR_ARG;
+  if (!c->cost_ready) return fail(c, CSPM_ERR_STATE, "no plane cost built (cspm_build_cost_grd / cspm_finish_cost)");
+  if (!*p) *p = &kDefaultParams;
+  if ((*p)->schedule != CSPM_SCHED_RASTER && (*p)->schedule != CSPM_SCHED_REDBLACK) return fail(c, CSPM_ERR_ARG, "bad schedule");
+  if ((*p)->rb_neighbours != 2 && (*p)->rb_neighbours != 4) return fail(c, CSPM_ERR_ARG, "rb_neighbours must be 2 or 4");
+  if ((*p)->rb_rounds < 1) return fail(c, CSPM_ERR_ARG, "rb_rounds must be >= 1");
+  return ensure_field(c);
+}
+
+#define LAUNCH_CS(kern, grid, block, shmem, ...)                                                   \
+  do {                                                                                             \
+    if (c->cost.cs) hipLaunchKernelGGL(kern<true>, grid, block, shmem, c->stream, __VA_ARGS__);    \
+    else hipLaunchKernelGGL(kern<false>, grid, block, shmem, c->stream, __VA_ARGS__);              \
+  } while (0)
+
+int do_init(cspm_ctx *c, const cspm_pm_params *p) {
+  const long long items = 2LL * c->W * c->H;
+  Pm pm = make_pm(c, p);
+  {
+    Timed t(c, CSPM_K_INIT, items);
+    LAUNCH_CS(k_init, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm);
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  Pm pm = make_pm(c, p);
+  const int inc = (iter % 2 == 0) ? 1 : -1;
+  if (p->schedule == CSPM_SCHED_REDBLACK) {
+    const long long items = 2LL * ((c->W + 1) / 2) * c->H;
+    for (int r = 0; r < p->rb_rounds; ++r)
+      for (int hs = 0; hs < 2; ++hs) {
+        Timed t(c, CSPM_K_SPATIAL, items * p->rb_neighbours);
+        LAUNCH_CS(k_spatial_rb, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, (hs + iter) & 1, inc, p->rb_neighbours);
+      }
+  } else {
+    for (int k = 1; k <= c->W + c->H - 2; ++k) {
+      const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
+      const long long items = 2LL * (ys_hi - ys_lo + 1);
+      Timed t(c, CSPM_K_SPATIAL, items * 2);
+      LAUNCH_CS(k_spatial_diag, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, k, inc);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  Pm pm = make_pm(c, p);
+  const long long items = (long long)c->W * c->H;
+  const size_t shmem = (size_t)c->W * (sizeof(unsigned long long) + sizeof(unsigned int));
+  if (shmem > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the view-propagation row resolver");
+  for (int v = 0; v < 2; ++v) {
+    {
+      Timed t(c, CSPM_K_VIEW, items);
+      LAUNCH_CS(k_view_eval, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, v, c->vc);
+    }
+    {
+      Timed t(c, CSPM_K_MISC, 0);
+      hipLaunchKernelGGL(k_view_resolve, dim3(c->H), dim3(256), shmem, c->stream, pm, v, iter % 2 == 0 ? 0 : 1, c->vc);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+int do_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  Pm pm = make_pm(c, p);
+  const long long items = 2LL * c->W * c->H;
+  double z_iter = c->max_dis / 2.0, n_iter = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145
+  int step = 0;
+  while (z_iter >= 0.1) {                          // kZStopThres_, cs_patchmatch.h:146
+    {
+      Timed t(c, CSPM_K_REFINE, items);
+      LAUNCH_CS(k_refine, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, iter, step, z_iter, n_iter);
+    }
+    z_iter /= 2.0;
+    n_iter /= 2.0;
+    ++step;
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int cspm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cspm_create(cspm_ctx **out, int device) {
+  if (!out) return CSPM_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, CSPM_ERR_HIP, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0"));
+  if (device < 0 || device >= n) return fail(nullptr, CSPM_ERR_ARG, "device index out of range");
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(nullptr, CSPM_ERR_HIP, std::string("libcspm_hip is built for gfx950 only, device is ") + prop.gcnArchName);
+  cspm_ctx *c = new cspm_ctx();
+  c->device = device;
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete c;
+    return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return CSPM_OK;
+}
+
+void cspm_destroy(cspm_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : c->pool) (void)hipEventDestroy(e);
+  free_cost(c);
+  free_field(c);
+  free_images(c);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char *cspm_last_error(const cspm_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int cspm_set_stream(cspm_ctx *c, void *s) {
+  if (!c) return CSPM_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return CSPM_OK;
+}
+
+int cspm_synchronize(cspm_ctx *c) {
+  if (!c) return CSPM_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
+}
+
+static int set_images_impl(cspm_ctx *c, const void *l, const void *r, int w, int h, size_t stride, bool on_device) {
+  if (!c) return CSPM_ERR_ARG;
+  if (!l || !r || w < 1 || h < 1 || stride < (size_t)w * 3) return fail(c, CSPM_ERR_ARG, "bad image arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (w != c->W || h != c->H) {
+    free_cost(c);
+    free_field(c);
+    free_images(c);
+    int rc;
+    for (int v = 0; v < 2; ++v)
+      if ((rc = dalloc(c, &c->img0[v], (size_t)w * h, nullptr))) return rc;
+    c->W = w; c->H = h;
+  } else {
+    c->cost_ready = false;
+  }
+  const void *src[2] = {l, r};
+  uint8_t *tmp = nullptr;
+  if (!on_device) HIPCHK(c, hipMalloc((void **)&tmp, stride * h));
+  for (int v = 0; v < 2; ++v) {
+    const uint8_t *d_src = (const uint8_t *)src[v];
+    if (!on_device) {
+      HIPCHK(c, hipMemcpyAsync(tmp, src[v], stride * h, hipMemcpyHostToDevice, c->stream));
+      d_src = tmp;
+    }
+    Timed t(c, CSPM_K_MISC, 0);
+    hipLaunchKernelGGL(k_pack_bgr, dim3(ew_grid((long long)w * h)), dim3(256), 0, c->stream, d_src, stride, w, h, c->img0[v]);
+    if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (tmp) (void)hipFree(tmp);
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+int cspm_set_images(cspm_ctx *c, const uint8_t *l, const uint8_t *r, int w, int h, size_t stride) {
+  return set_images_impl(c, l, r, w, h, stride, false);
+}
+int cspm_set_images_device(cspm_ctx *c, const void *l, const void *r, int w, int h, size_t stride) {
+  return set_images_impl(c, l, r, w, h, stride, true);
+}
+
+int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+  if (!c) return CSPM_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda);
+  if (rc) return rc;
+  Cost &cd = c->cost;
+  // gradients of both views per level (grd_cc.cpp:70-77), then both volumes (pre_cs_pc.cc:57-84)
+  std::vector<void *> tmp;
+  for (int s = 0; s < cd.levels; ++s) {
+    const Level &L = cd.lv[s];
+    const long long px = (long long)L.W * L.H;
+    double *g[2];
+    for (int v = 0; v < 2; ++v) {
+      if ((rc = dalloc(c, &g[v], (size_t)px, &tmp))) return rc;
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.img[v]}, L.W, L.H, g[v]);
+    }
+    const long long cells = px * (L.D + 1);
+    for (int v = 0; v < 2; ++v) {
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(ew_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.img[0]}, SrcU32{L.img[1]},
+                         g[0], g[1], L.W, L.H, L.D + 1, v, (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  rc = finish_cost(c);
+  for (void *p : tmp) (void)hipFree(p);
+  return rc;
+}
+
+int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+  if (!c) return CSPM_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda);
+  if (rc) return rc;
+  for (int s = 0; s < c->cost.levels; ++s)
+    for (int v = 0; v < 2; ++v) {
+      const Level &L = c->cost.lv[s];
+      HIPCHK(c, hipMemsetAsync((void *)L.vol[v], 0, sizeof(double) * (size_t)(L.D + 1) * L.W * L.H, c->stream));  // Mat::zeros, pre_cs_pc.cc:52
+    }
+  return CSPM_OK;
+}
+
+int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double *slab, size_t stride_elems) {
+  if (!c) return CSPM_ERR_ARG;
+  if (!c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (view < 0 || view > 1 || level < 0 || level >= c->cost.levels || !slab) return fail(c, CSPM_ERR_ARG, "bad view/level/slab");
+  const Level &L = c->cost.lv[level];
+  if (d < 0 || d > L.D || stride_elems < (size_t)L.W) return fail(c, CSPM_ERR_ARG, "bad slab index or stride");
+  double *dst = (double *)L.vol[view] + (size_t)d * L.W * L.H;
+  HIPCHK(c, hipMemcpy2DAsync(dst, sizeof(double) * L.W, slab, sizeof(double) * stride_elems, sizeof(double) * L.W, L.H,
+                             hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse the slab buffer
+  c->cost_ready = false;
+  return CSPM_OK;
+}
+
+int cspm_finish_cost(cspm_ctx *c) {
+  if (!c) return CSPM_ERR_ARG;
+  if (!c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
+  for (int s = 0; s < c->cost.levels; ++s)
+    for (int v = 0; v < 2; ++v) {
+      const Level &L = c->cost.lv[s];
+      const long long cells = (long long)(L.D + 1) * L.W * L.H;
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_volume_max, dim3(2048), dim3(256), 0, c->stream, L.vol[v], cells, c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+    }
+  HIPCHK(c, hipGetLastError());
+  return finish_cost(c);
+}
+
+int cspm_get_levels(const cspm_ctx *c) { return (c && c->cost_alloc) ? c->cost.levels : 0; }
+
+int cspm_get_level_dims(const cspm_ctx *c, int level, int *w, int *h, int *max_disp) {
+  if (!c || !c->cost_alloc || level < 0 || level >= c->cost.levels) return CSPM_ERR_ARG;
+  if (w) *w = c->cost.lv[level].W;
+  if (h) *h = c->cost.lv[level].H;
+  if (max_disp) *max_disp = c->cost.lv[level].D;
+  return CSPM_OK;
+}
+
+int cspm_get_level_image(cspm_ctx *c, int view, int level, uint8_t *out) {
+  if (!c || !out) return CSPM_ERR_ARG;
+  if (!c->cost_alloc || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_ARG, "bad view/level");
+  const Level &L = c->cost.lv[level];
+  const size_t px = (size_t)L.W * L.H;
+  uint8_t *tmp;
+  HIPCHK(c, hipMalloc((void **)&tmp, px * 3));
+  hipLaunchKernelGGL(k_unpack_bgr, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, L.img[view], L.W, L.H, tmp);
+  HIPCHK(c, hipMemcpyAsync(out, tmp, px * 3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(tmp);
+  return CSPM_OK;
+}
+
+int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
+  if (!c || !out) return CSPM_ERR_ARG;
+  if (!c->cost_alloc || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_ARG, "bad view/level");
+  const Level &L = c->cost.lv[level];
+  if (d < 0 || d > L.D) return fail(c, CSPM_ERR_ARG, "bad slab index");
+  HIPCHK(c, hipMemcpyAsync(out, L.vol[view] + (size_t)d * L.W * L.H, sizeof(double) * (size_t)L.W * L.H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
+}
+
+int cspm_get_max_cost(cspm_ctx *c, int view, int level, double *out) {
+  if (!c || !out) return CSPM_ERR_ARG;
+  if (!c->cost_ready || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_STATE, "cost not ready or bad view/level");
+  *out = c->host_max_cost[view * CSPM_MAX_LEVELS + level];
+  return CSPM_OK;
+}
+
+int cspm_get_scale_weights(const cspm_ctx *c, double *out) {
+  if (!c || !out || !c->cost_alloc) return CSPM_ERR_ARG;
+  for (int s = 0; s < c->cost.levels; ++s) out[s] = c->scale_wgt[s];
+  return CSPM_OK;
+}
+
+int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, int right_view, double *vol_out) {
+  if (!l_rgb || !r_rgb || !vol_out || w < 1 || h < 1 || maxDis < 1) return fail(nullptr, CSPM_ERR_ARG, "bad arguments");
+  cspm_ctx *c = nullptr;
+  int rc = cspm_create(&c, device);
+  if (rc) return rc;
+  const size_t px = (size_t)w * h;
+  double *dl = nullptr, *dr = nullptr, *gl = nullptr, *gr = nullptr, *vol = nullptr;
+  unsigned long long *key = nullptr;
+  std::vector<void *> tmp;
+  auto done = [&](int code) {
+    if (code) g_create_error = c->err;
+    for (void *p : tmp) (void)hipFree(p);
+    cspm_destroy(c);
+    return code;
+  };
+  if ((rc = dalloc(c, &dl, px * 3, &tmp)) || (rc = dalloc(c, &dr, px * 3, &tmp)) || (rc = dalloc(c, &gl, px, &tmp)) ||
+      (rc = dalloc(c, &gr, px, &tmp)) || (rc = dalloc(c, &vol, px * maxDis, &tmp)) || (rc = dalloc(c, &key, 1, &tmp)))
+    return done(rc);
+  if (hipMemcpyAsync(dl, l_rgb, sizeof(double) * px * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(dr, r_rgb, sizeof(double) * px * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemsetAsync(key, 0, sizeof *key, c->stream) != hipSuccess)
+    return done(fail(c, CSPM_ERR_HIP, "upload failed"));
+  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dl}, w, h, gl);
+  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dr}, w, h, gr);
+  hipLaunchKernelGGL(k_grd_volume<SrcF64>, dim3(ew_grid((long long)px * maxDis)), dim3(256), 0, c->stream, SrcF64{dl}, SrcF64{dr}, gl, gr,
+                     w, h, maxDis, right_view, vol, key);
+  if (hipMemcpyAsync(vol_out, vol, sizeof(double) * px * maxDis, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+    return done(fail(c, CSPM_ERR_HIP, "GRD volume kernel failed"));
+  return done(CSPM_OK);
+}
+
+int cspm_plane_cost_batch(cspm_ctx *c, int view, int n, const int *xy, const double *np, double *out) {
+  if (!c) return CSPM_ERR_ARG;
+  if (!c->cost_ready) return fail(c, CSPM_ERR_STATE, "no plane cost built");
+  if (view < 0 || view > 1 || n < 0 || (n && (!xy || !np || !out))) return fail(c, CSPM_ERR_ARG, "bad arguments");
+  if (n == 0) return CSPM_OK;
+  for (int i = 0; i < n; ++i)
+    if (xy[2 * i] < 0 || xy[2 * i] >= c->W || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= c->H) return fail(c, CSPM_ERR_ARG, "pixel outside the image");
+  HIPCHK(c, hipSetDevice(c->device));
+  int *dxy = nullptr;
+  double *dnp = nullptr, *dout = nullptr;
+  std::vector<void *> tmp;
+  int rc;
+  if ((rc = dalloc(c, &dxy, (size_t)2 * n, &tmp)) || (rc = dalloc(c, &dnp, (size_t)6 * n, &tmp)) || (rc = dalloc(c, &dout, (size_t)n, &tmp))) {
+    for (void *p : tmp) (void)hipFree(p);
+    return rc;
+  }
+  hipError_t e = hipMemcpyAsync(dxy, xy, sizeof(int) * 2 * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dnp, np, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    LAUNCH_CS(k_cost_batch, dim3(eval_grid(n)), dim3(kEvalBlock), 0, c->cost, view, n, dxy, dnp, dout);
+    e = hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  for (void *p : tmp) (void)hipFree(p);
+  if (e != hipSuccess) return fail(c, CSPM_ERR_HIP, hipGetErrorString(e));
+  return CSPM_OK;
+}
+
+int cspm_pm_default_params(cspm_pm_params *p) {
+  if (!p) return CSPM_ERR_ARG;
+  *p = kDefaultParams;
+  return CSPM_OK;
+}
+
+int cspm_pm_init(cspm_ctx *c, const cspm_pm_params *p) {
+  int rc = check_pm(c, &p);
+  return rc ? rc : do_init(c, p);
+}
+int cspm_pm_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  int rc = check_pm(c, &p);
+  return rc ? rc : do_spatial(c, iter, p);
+}
+int cspm_pm_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  int rc = check_pm(c, &p);
+  return rc ? rc : do_view(c, iter, p);
+}
+int cspm_pm_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
+  int rc = check_pm(c, &p);
+  return rc ? rc : do_refine(c, iter, p);
+}
+
+int cspm_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
+  int rc = check_pm(c, &p);
+  if (rc) return rc;
+  if (iter_num < 0 || iter_num > 15) return fail(c, CSPM_ERR_ARG, "iter_num out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = do_init(c, p))) return rc;                 // cs_patchmatch.cc:55
+  for (int i = 0; i < iter_num; ++i) {                 // :65-102
+    if ((rc = do_spatial(c, i, p))) return rc;
+    if ((rc = do_view(c, i, p))) return rc;
+    if ((rc = do_refine(c, i, p))) return rc;
+  }
+  return CSPM_OK;
+}
+
+int cspm_get_planes(cspm_ctx *c, int view, double *np_out, double *cost_out) {
+  if (!c || view < 0 || view > 1) return CSPM_ERR_ARG;
+  if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  const size_t n = (size_t)c->W * c->H;
+  std::vector<double> h(7 * n);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->f[view].nx, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (np_out)
+    for (size_t i = 0; i < n; ++i)
+      for (int k = 0; k < 6; ++k) np_out[6 * i + k] = h[k * n + i];
+  if (cost_out) memcpy(cost_out, h.data() + 6 * n, sizeof(double) * n);
+  return CSPM_OK;
+}
+
+int cspm_set_planes(cspm_ctx *c, int view, const double *np, const double *cost) {
+  if (!c || view < 0 || view > 1 || !np || !cost) return CSPM_ERR_ARG;
+  if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images first");
+  int rc = ensure_field(c);
+  if (rc) return rc;
+  const size_t n = (size_t)c->W * c->H;
+  std::vector<double> h(7 * n);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 6; ++k) h[k * n + i] = np[6 * i + k];
+  memcpy(h.data() + 6 * n, cost, sizeof(double) * n);
+  HIPCHK(c, hipMemcpyAsync(c->f[view].nx, h.data(), sizeof(double) * 7 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
+}
+
+int cspm_disparity_u8_device(cspm_ctx *c, int view, int dis_scale, void *d_out) {
+  if (!c || view < 0 || view > 1 || !d_out) return CSPM_ERR_ARG;
+  if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
+  {
+    Timed t(c, CSPM_K_MISC, 0);
+    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid((long long)c->W * c->H)), dim3(256), 0, c->stream, pm, view, dis_scale,
+                       (uint8_t *)d_out, (size_t)c->W);
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+int cspm_get_disparity_u8(cspm_ctx *c, int view, int dis_scale, uint8_t *out, size_t stride) {
+  if (!c || !out || stride < (size_t)c->W) return CSPM_ERR_ARG;
+  int rc = cspm_disparity_u8_device(c, view, dis_scale, c->d_dis[view < 0 || view > 1 ? 0 : view]);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy2DAsync(out, stride, c->d_dis[view], c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
+}
+
+int cspm_get_disparity_f64(cspm_ctx *c, int view, double *out) {
+  if (!c || view < 0 || view > 1 || !out) return CSPM_ERR_ARG;
+  if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
+  const size_t n = (size_t)c->W * c->H;
+  hipLaunchKernelGGL(k_plane_to_disp_f64, dim3(ew_grid((long long)n)), dim3(256), 0, c->stream, pm, view, c->vc.cost);
+  HIPCHK(c, hipMemcpyAsync(out, c->vc.cost, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
+}
+
+int cspm_postprocess(cspm_ctx *c, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride) {
+  (void)dis_scale; (void)l_out; (void)r_out; (void)stride;
+  return fail(c, CSPM_ERR_STATE, "cspm_postprocess: not implemented yet (SURVEY.md 8(f) rank 1)");
+}
+
+int cspm_enable_timing(cspm_ctx *c, int on) {
+  if (!c) return CSPM_ERR_ARG;
+  c->timing = on != 0;
+  return CSPM_OK;
+}
+int cspm_reset_timing(cspm_ctx *c) {
+  if (!c) return CSPM_ERR_ARG;
+  int rc = drain_timing(c);
+  for (int k = 0; k < CSPM_K_COUNT; ++k) { c->acc_ms[k] = 0; c->acc_launch[k] = 0; c->acc_evals[k] = 0; }
+  return rc;
+}
+int cspm_get_timing(cspm_ctx *c, int k, long long *launches, double *total_ms, long long *evals) {
+  if (!c || k < 0 || k >= CSPM_K_COUNT) return CSPM_ERR_ARG;
+  int rc = drain_timing(c);
+  if (launches) *launches = c->acc_launch[k];
+  if (total_ms) *total_ms = c->acc_ms[k];
+  if (evals) *evals = c->acc_evals[k];
+  return rc;
+}
+
+long long cspm_taps_per_view_pass(const cspm_ctx *c) {
+  if (!c || !c->cost_alloc) return 0;
+  long long total = 0;
+  const Cost &cd = c->cost;
+  for (int s = 0; s < cd.levels; ++s) {
+    const Level &L = cd.lv[s];
+    long long sx = 0, sy = 0;
+    for (int x = 0; x < c->W; ++x) {
+      const int cx = x >> s;
+      sx += std::min(cx + cd.half, L.W - 1) - std::max(cx - cd.half, 0) + 1;
+    }
+    for (int y = 0; y < c->H; ++y) {
+      const int cy = y >> s;
+      sy += std::min(cy + cd.half, L.H - 1) - std::max(cy - cd.half, 0) + 1;
+    }
+    total += sx * sy;
+  }
+  return total;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// cspm_device.h -- device-side data layout and the scalar building blocks shared by all kernels.
+// gfx950 only.  Compiled with -ffp-contract=off: every product and sum is individually rounded so
+// that results are bit-identical to the (SSE2, no-FMA) reference arithmetic restated in oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cspm.h"
+
+#pragma clang fp contract(off)
+
+namespace cspm {
+
+constexpr double kDoubleEps = 0.00000001;  // commfunc.h:26
+constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_limits<double>::max()
+constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
+constexpr int kWave = 64;
+constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup
+constexpr int kCheckEvery = 4;             // early-exit checkpoint every 4 tap groups (and at level end)
+
+// One pyramid level of one PreSSPC/PreCSPC object (pre_cs_pc.h:41-56).
+struct Level {
+  int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
+  const uint32_t *img[2]; // packed B | G<<8 | R<<16 (byte 3 = 0), row-major H*W
+  const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major
+  double wgt;             // scale_wgt_[s]
+};
+
+struct Cost {
+  int cs;      // 0: PreSSPC::GetPlaneCost, 1: PreCSPC::GetPlaneCost
+  int levels;
+  int half;    // half_wnd_
+  int n;       // 2*half+1
+  int T;       // n*n taps
+  int groups;  // ceil(T/64)
+  int early_ok;           // all scale weights and max_costs are >= 0
+  const double *lut;      // lookup_exp_[i] = exp(-i/10), host-computed, kLutSize entries
+  const double *max_cost; // device, [view*CSPM_MAX_LEVELS + level]
+  Level lv[CSPM_MAX_LEVELS];
+};
+
+// Plane field of one view, structure of arrays (replaces Plane** plane_[v] / double** min_cost_[v],
+// cs_patchmatch.h:139-142).  Plane::point_ is not stored: it only feeds update_param().
+struct Field {
+  double *nx, *ny, *nz; // Plane::norm_
+  double *a, *b, *c;    // Plane::param_
+  double *cost;         // min_cost_
+};
+
+struct Pm {
+  int W, H, max_dis;
+  uint64_t seed;
+  int rng_row_shared;
+  int use_thresh; // early exit enabled
+  Field f[2];
+};
+
+// ---- commfunc.h:117-121 Round2Int: magic-number round-half-even ----
+__device__ __forceinline__ int round2int(double d) {
+  d = d + 6755399441055744.0;
+  return __double2loint(d);
+}
+// ---- commfunc.h:129-145 ----
+__device__ __forceinline__ int handle_border(int loc, int size) {
+  if (loc < 0) return loc + size;
+  if (loc >= size) return loc - size;
+  return loc;
+}
+
+// ---- plane.h:25-34 Plane::update_param (dot product in cv::Matx::dot order) ----
+__device__ __forceinline__ void plane_param(double nx, double ny, double nz, double px, double py, double pz,
+                                            double &a, double &b, double &c) {
+  double denom = fmax(fabs(nz), kDoubleEps);
+  if (nz < 0.0) denom = -denom;
+  a = -nx / denom;
+  b = -ny / denom;
+  double s = nx * px;
+  s += ny * py;
+  s += nz * pz;
+  c = s / denom;
+}
+
+// ---- counter-based RNG (specification in DESIGN.md "RNG"; the oracle implements the same spec) ----
+constexpr uint64_t kGold = 0x9E3779B97F4A7C15ULL;
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+  z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return z;
+}
+__host__ __device__ __forceinline__ uint32_t stream_id(int phase, int iter, int step, int view) {
+  return (uint32_t)((((phase * 16 + iter) * 32 + step) * 2) + view);
+}
+struct Rng {
+  uint64_t base;
+  __device__ __forceinline__ Rng(uint64_t seed, uint32_t stream, uint64_t pix) {
+    uint64_t k = mix64(seed + kGold * ((uint64_t)stream + 1));
+    base = mix64(k ^ (kGold * (pix + 1)));
+  }
+  __device__ __forceinline__ double u01(uint32_t draw) const {
+    uint64_t r = mix64(base + kGold * ((uint64_t)draw + 1));
+    return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+  }
+  // cv::RNG::uniform(a,b) = u*(b-a)+a
+  __device__ __forceinline__ double uniform(uint32_t draw, double a, double b) const { return u01(draw) * (b - a) + a; }
+};
+
+// sum over the 64 lanes: xor butterfly with ascending offsets 1,2,4,8,16,32 (the LANE64 order of the
+// oracle).  Every lane ends with the same bits because a+b == b+a.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// order-preserving map double -> uint64 (for atomic min/max on costs of either sign)
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ __forceinline__ double key_f64(unsigned long long k) {
+  unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+  union { unsigned long long u; double d; } x;
+  x.u = b;
+  return x.d;
+}
+
+}  // namespace cspm

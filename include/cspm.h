@@ -1,0 +1,138 @@
+/*
+ * cspm.h -- C ABI of libcspm_hip.so: the MI355X (gfx950) implementation of the PatchMatch-stereo
+ * hot path of rookiepig/CrossScalePatchMatch (GRD plane cost, single-scale and cross-scale).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference's
+ * CSPM/ directory).  Conventions:
+ *   - extern "C", plain pointers and sizes, no C++/torch types; int status: 0 = OK, < 0 = error
+ *     (cspm_last_error() gives the text); no exceptions cross the boundary.
+ *   - a cspm_ctx owns all device memory of ONE stereo pair on ONE GPU and ONE HIP stream; it is not
+ *     thread-safe; use one ctx per host thread / stream.  Host buffers are caller-owned.
+ *   - "view": 0 = left (kLeft), 1 = right (kRight)  (commfunc.h:29).
+ *   - images are packed 8UC3 BGR, the layout cv::imread(CV_LOAD_IMAGE_COLOR) returns (main.cc:68-69).
+ *   - the library has no CPU fallback: every call fails with CSPM_ERR_HIP when no gfx950 device is
+ *     usable.
+ */
+#ifndef CSPM_H
+#define CSPM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSPM_OK 0
+#define CSPM_ERR_ARG (-1)   /* bad argument (the reference CV_Asserts or crashes) */
+#define CSPM_ERR_HIP (-2)   /* HIP runtime error, no device, out of memory */
+#define CSPM_ERR_STATE (-3) /* call order violated (e.g. patchmatch before a cost is built) */
+
+#define CSPM_MAX_LEVELS 8
+
+typedef struct cspm_ctx cspm_ctx;
+
+/* SpatialPropagation schedule (cs_patchmatch.cc:163-216) */
+#define CSPM_SCHED_RASTER 0   /* reference order: in-place raster sweep, run as an anti-diagonal wavefront */
+#define CSPM_SCHED_REDBLACK 1 /* checkerboard half-steps (fast path) */
+
+/* rng flags */
+#define CSPM_RNG_PER_PIXEL 0
+#define CSPM_RNG_ROW_SHARED 1 /* the USE_OMP per-row re-seeding quirk (cs_patchmatch.cc:129-131,308-310) */
+
+typedef struct cspm_pm_params {
+  uint64_t seed;     /* replaces RNG(time(NULL)), cs_patchmatch.cc:32 */
+  int schedule;      /* CSPM_SCHED_* */
+  int rb_rounds;     /* red-black rounds per iteration (>= 1) */
+  int rb_neighbours; /* 2 or 4 */
+  int rng_mode;      /* CSPM_RNG_* */
+  int early_exit;    /* 1: stop a plane evaluation once its partial sum proves cost >= min_cost
+                        (result-preserving; ignored when a scale weight or max_cost is negative) */
+} cspm_pm_params;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int cspm_device_count(void);
+int cspm_create(cspm_ctx **out, int device);
+void cspm_destroy(cspm_ctx *ctx);
+const char *cspm_last_error(const cspm_ctx *ctx); /* ctx may be NULL: error of a failed cspm_create */
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+int cspm_set_stream(cspm_ctx *ctx, void *hip_stream);
+int cspm_synchronize(cspm_ctx *ctx);
+
+/* ---- images: PreSSPC/PreCSPC/CSPatchMatch constructors' (l_img, r_img) ----------------------
+ * pre_ss_pc.cc:12-30, pre_cs_pc.cc:12-30, cs_patchmatch.cc:3-11.  stride in bytes (>= 3*w). */
+int cspm_set_images(cspm_ctx *ctx, const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h, size_t stride);
+/* same, from device memory already resident in HBM (bench / batch driver) */
+int cspm_set_images_device(cspm_ctx *ctx, const void *d_l_bgr, const void *d_r_bgr, int w, int h, size_t stride);
+
+/* ---- plane cost construction ------------------------------------------------------------------
+ * cspm_build_cost_grd = `new PreSSPC(l,r,max_dis,wnd,new GrdCC)` when scale_num == 0
+ * (pre_ss_pc.cc:12-65) and `new PreCSPC(l,r,max_dis,wnd,scale_num,new GrdCC,reg_lambda)` when
+ * scale_num >= 1 (pre_cs_pc.cc:12-115): pyramid, per-level GRD cost volumes of both views
+ * (cc/grd_cc.cpp:60-154), max_cost, scale weights, exp LUT -- all on the device. */
+int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
+/* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
+ * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */
+int cspm_begin_cost(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
+int cspm_upload_cost_slab(cspm_ctx *ctx, int view, int level, int d, const double *slab, size_t stride_elems);
+int cspm_finish_cost(cspm_ctx *ctx);
+/* introspection of what the constructor built (parity hooks) */
+int cspm_get_levels(const cspm_ctx *ctx);
+int cspm_get_level_dims(const cspm_ctx *ctx, int level, int *w, int *h, int *max_disp);
+int cspm_get_level_image(cspm_ctx *ctx, int view, int level, uint8_t *bgr_out);     /* packed w*h*3 */
+int cspm_get_cost_slab(cspm_ctx *ctx, int view, int level, int d, double *slab_out); /* packed w*h */
+int cspm_get_max_cost(cspm_ctx *ctx, int view, int level, double *out);
+int cspm_get_scale_weights(const cspm_ctx *ctx, double *out /* levels */);
+
+/* CCMethod::buildCV / buildRightCV on host buffers (cc_method.h:31-32, cc/grd_cc.cpp:60-154):
+ * l_rgb/r_rgb are h*w*3 doubles (CV_64FC3, RGB, 0..255), vol_out receives maxDis slabs of h*w. */
+int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis,
+                           int right_view, double *vol_out);
+
+/* ---- IPlaneCost::GetPlaneCost, batched (plane_cost/i_plane_cost.h:28-33) ----------------------
+ * xy: 2 ints per item; plane: 6 doubles per item = Plane::norm() then Plane::param().
+ * Summation order is the device order (DESIGN.md "LANE64"); differs from the reference's serial
+ * sum only by rounding. */
+int cspm_plane_cost_batch(cspm_ctx *ctx, int view, int n, const int *xy, const double *norm_param, double *cost_out);
+
+/* ---- CSPatchMatch ------------------------------------------------------------------------------
+ * cspm_patchmatch = CSPatchMatch::PatchMatch(iter_num, plane_cost, false) without PlaneToDisp
+ * (cs_patchmatch.cc:51-102); max_dis / images are those of the ctx. */
+int cspm_pm_default_params(cspm_pm_params *p);
+int cspm_patchmatch(cspm_ctx *ctx, int iter_num, const cspm_pm_params *p);
+/* single phases (cs_patchmatch.cc:115-148, 163-216, 229-277, 292-345) for phase-by-phase parity */
+int cspm_pm_init(cspm_ctx *ctx, const cspm_pm_params *p);
+int cspm_pm_spatial(cspm_ctx *ctx, int iter, const cspm_pm_params *p);
+int cspm_pm_view(cspm_ctx *ctx, int iter, const cspm_pm_params *p);
+int cspm_pm_refine(cspm_ctx *ctx, int iter, const cspm_pm_params *p);
+/* plane field in/out: 6 doubles per pixel (norm, param), row-major h*w; min_cost h*w doubles */
+int cspm_get_planes(cspm_ctx *ctx, int view, double *norm_param_out, double *min_cost_out);
+int cspm_set_planes(cspm_ctx *ctx, int view, const double *norm_param, const double *min_cost);
+/* PlaneToDisp + dis() (cs_patchmatch.cc:590-601, 111-113): saturate_u8(Round2Int(d*dis_scale)) */
+int cspm_get_disparity_u8(cspm_ctx *ctx, int view, int dis_scale, uint8_t *out, size_t stride);
+int cspm_get_disparity_f64(cspm_ctx *ctx, int view, double *out); /* unquantised a*x+b*y+c */
+/* device-resident result (u8, packed w*h) for the batch driver */
+int cspm_disparity_u8_device(cspm_ctx *ctx, int view, int dis_scale, void *d_out);
+/* PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps */
+int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride);
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by hipEvents on the ctx stream. */
+#define CSPM_K_GRD 0      /* cost-volume construction kernels */
+#define CSPM_K_INIT 1     /* plane cost evaluation: random init */
+#define CSPM_K_SPATIAL 2  /* plane cost evaluation: spatial propagation */
+#define CSPM_K_VIEW 3     /* plane cost evaluation: view propagation */
+#define CSPM_K_REFINE 4   /* plane cost evaluation: plane refinement (the dominant kernel) */
+#define CSPM_K_MISC 5     /* pyramid, resolve, disparity, ... */
+#define CSPM_K_COUNT 6
+int cspm_enable_timing(cspm_ctx *ctx, int on);
+int cspm_reset_timing(cspm_ctx *ctx);
+/* launches, summed milliseconds and summed evaluated candidate planes of a kernel class */
+int cspm_get_timing(cspm_ctx *ctx, int kclass, long long *launches, double *total_ms, long long *evals);
+/* exact in-image window taps of ONE evaluation of every pixel of one view (sum over pixels, levels) */
+long long cspm_taps_per_view_pass(const cspm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,125 @@
+"""GPU parity, cost side: pyramid (pre_cs_pc.cc:36-55), GRD volumes (cc/grd_cc.cpp:60-154), max_cost,
+scale weights, and batched IPlaneCost::GetPlaneCost (pre_ss_pc.cc:74-118, pre_cs_pc.cc:133-188) --
+HIP path through the C ABI vs the oracle, bit-exact (f64 arithmetic, same operation order)."""
+import numpy as np
+import pytest
+
+from conftest import random_planes
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("ss", 0, 0.0), ("cs0", 5, 0.0), ("cs03", 5, 0.3), ("cs1", 5, 1.0), ("cs3lv", 3, 0.3)]
+
+
+def _build(ctx, pair, scale_num, lam, wnd=35):
+    ctx.set_images(pair["l"], pair["r"])
+    ctx.build_cost_grd(pair["max_dis"], wnd, scale_num, lam)
+    return po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], wnd, scale_num, lam)
+
+
+@pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
+@pytest.mark.parametrize("name,scale_num,lam", CASES)
+def test_pyramid_volumes_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam):
+    pair = request.getfixturevalue(pairname)
+    pc = _build(gpu_ctx, pair, scale_num, lam)
+    assert gpu_ctx.levels == pc.levels
+    np.testing.assert_array_equal(gpu_ctx.scale_weights(), pc.scale_wgt())
+    for s in range(pc.levels):
+        assert gpu_ctx.level_dims(s) == pc.dims(s)
+        for v in (0, 1):
+            np.testing.assert_array_equal(gpu_ctx.level_image(v, s), pc.image(v, s))
+            np.testing.assert_array_equal(gpu_ctx.cost_volume(v, s), pc.volume(v, s))
+            assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
+
+
+def test_grd_build_cv_host_boundary(small_pair):
+    """CCMethod::buildCV / buildRightCV on caller-owned CV_64FC3 buffers (cc_method.h:31-32)."""
+    import ctypes as C
+    import crossscalepatchmatch_amd as cs
+    L = cs.load_library()
+    lib = po.lib()
+    h, w, D = small_pair["h"], small_pair["w"], small_pair["max_dis"] + 1
+    rng = np.random.default_rng(5)
+    # arbitrary doubles, not only u8-valued ones: the boundary takes CV_64FC3
+    l = small_pair["l"][..., ::-1].astype(np.float64) + rng.uniform(-0.4, 0.4, (h, w, 3))
+    r = small_pair["r"][..., ::-1].astype(np.float64) + rng.uniform(-0.4, 0.4, (h, w, 3))
+    l, r = np.ascontiguousarray(l), np.ascontiguousarray(r)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for right in (0, 1):
+        got = np.zeros((D, h, w))
+        want = np.zeros((D, h, w))
+        rc = L.cspm_grd_build_cv_host(0, dp(l), dp(r), w, h, D, right, dp(got))
+        assert rc == 0, L.cspm_last_error(None)
+        (lib.csor_grd_build_right_cv if right else lib.csor_grd_build_cv)(dp(l), dp(r), w, h, D, dp(want))
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
+@pytest.mark.parametrize("name,scale_num,lam", CASES)
+def test_plane_cost_batch(gpu_ctx, request, pairname, name, scale_num, lam):
+    """T2: >= 10^4 random (x, y, plane, view) tuples incl. corners, |nz|~0, out-of-range disparities."""
+    pair = request.getfixturevalue(pairname)
+    pc = _build(gpu_ctx, pair, scale_num, lam)
+    rng = np.random.default_rng(99)
+    n = 5200
+    for view in (0, 1):
+        xy, norm, point, param = random_planes(rng, n, pair["w"], pair["h"], pair["max_dis"])
+        got = gpu_ctx.plane_cost_batch(view, xy, np.concatenate([norm, param], 1))
+        lane = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], view, po.SUM_LANE64) for i in range(n)])
+        np.testing.assert_array_equal(got, lane)  # same summation order: bit-exact
+        idx = rng.choice(n, 600, replace=False)
+        idx[:14] = np.arange(14)
+        ser = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], view, po.SUM_SERIAL) for i in idx])
+        np.testing.assert_allclose(got[idx], ser, rtol=1e-12, atol=0)  # reference order: rounding only
+
+
+def test_small_window(gpu_ctx, small_pair):
+    """wnd_size is a constructor argument (pre_ss_pc.h:20-22); 35 is only main.cc's constant."""
+    for wnd in (1, 3, 9, 35, 41):
+        pc = _build(gpu_ctx, small_pair, 3, 0.3, wnd)
+        rng = np.random.default_rng(wnd)
+        xy, norm, point, param = random_planes(rng, 64, small_pair["w"], small_pair["h"], small_pair["max_dis"])
+        got = gpu_ctx.plane_cost_batch(0, xy, np.concatenate([norm, param], 1))
+        want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 0, po.SUM_LANE64) for i in range(64)])
+        np.testing.assert_array_equal(got, want)
+
+
+def test_foreign_cost_volume_upload(gpu_ctx, small_pair):
+    """A CCMethod plugin the library knows nothing about: host volumes uploaded slab by slab."""
+    pc = po.PlaneCost(small_pair["l"], small_pair["r"], small_pair["max_dis"], 35, 3, 0.3)
+    rng = np.random.default_rng(3)
+    for s in range(pc.levels):
+        for v in (0, 1):
+            vol = pc.volume(v, s)
+            vol[...] = rng.uniform(0.0, 5.0, vol.shape)  # overwrite the oracle's volumes in place
+    pc.refresh_max_cost()
+    gpu_ctx.set_images(small_pair["l"], small_pair["r"])
+    gpu_ctx.begin_cost(small_pair["max_dis"], 35, 3, 0.3)
+    for s in range(pc.levels):
+        for v in (0, 1):
+            vol = pc.volume(v, s)
+            for d in range(vol.shape[0]):
+                gpu_ctx.upload_cost_slab(v, s, d, vol[d])
+    gpu_ctx.finish_cost()
+    for s in range(pc.levels):
+        for v in (0, 1):
+            assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
+    xy, norm, point, param = random_planes(rng, 256, small_pair["w"], small_pair["h"], small_pair["max_dis"])
+    got = gpu_ctx.plane_cost_batch(1, xy, np.concatenate([norm, param], 1))
+    want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 1, po.SUM_LANE64) for i in range(256)])
+    np.testing.assert_array_equal(got, want)
+
+
+def test_errors(gpu_ctx, small_pair):
+    import crossscalepatchmatch_amd as cs
+    gpu_ctx.set_images(small_pair["l"], small_pair["r"])
+    with pytest.raises(cs.CspmError):
+        gpu_ctx.build_cost_grd(0, 35, 0, 0.0)       # max_dis < 1
+    with pytest.raises(cs.CspmError):
+        gpu_ctx.build_cost_grd(16, 35, 99, 0.0)     # too many levels
+    with pytest.raises(cs.CspmError):
+        gpu_ctx.patchmatch(3)                        # no cost built (state error, not a crash)
+    gpu_ctx.build_cost_grd(16, 35, 0, 0.0)
+    with pytest.raises(cs.CspmError):
+        gpu_ctx.plane_cost_batch(0, [[999, 0]], [[0, 0, 1, 0, 0, 5]])  # pixel outside the image

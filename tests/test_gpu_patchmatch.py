@@ -1,0 +1,112 @@
+"""GPU parity, PatchMatch side (cs_patchmatch.cc:51-345, 590-601): every phase and the whole pipeline
+through the C ABI vs the oracle run with the same schedule, RNG and summation order -- bit-exact
+planes, costs and 8-bit disparity maps.  Plus the north-star bar against the reference-order oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+MODES = [("ss", 0, 0.0), ("cs", 5, 0.3)]
+
+
+def _setup(ctx, pair, scale_num, lam):
+    ctx.set_images(pair["l"], pair["r"])
+    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam)
+    pc = po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], 35, scale_num, lam)
+    pm = po.PatchMatch(pair["l"], pair["r"], pair["max_dis"], 4)
+    return pc, pm
+
+
+def _assert_state_equal(ctx, pm, what):
+    for v in (0, 1):
+        npar, cost = ctx.get_planes(v)
+        P = pm.planes(v)
+        np.testing.assert_array_equal(npar[..., :3], P[..., 0:3], err_msg=f"{what}: norm, view {v}")
+        np.testing.assert_array_equal(npar[..., 3:], P[..., 6:9], err_msg=f"{what}: param, view {v}")
+        np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"{what}: min_cost, view {v}")
+
+
+@pytest.mark.parametrize("name,scale_num,lam", MODES)
+@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
+def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched):
+    pc, pm = _setup(gpu_ctx, small_pair, scale_num, lam)
+    kw_o = dict(seed=777, schedule=sched, sum_order=po.SUM_LANE64, rb_rounds=2, rb_neighbours=4)
+    kw_g = dict(seed=777, schedule=sched, rb_rounds=2, rb_neighbours=4, early_exit=1)
+    pm.init(pc, **kw_o); gpu_ctx.pm_init(**kw_g)
+    _assert_state_equal(gpu_ctx, pm, "init")
+    for it in (0, 1):
+        pm.spatial(it, pc, **kw_o); gpu_ctx.pm_spatial(it, **kw_g)
+        _assert_state_equal(gpu_ctx, pm, f"spatial {it}")
+        pm.view(it, pc, **kw_o); gpu_ctx.pm_view(it, **kw_g)
+        _assert_state_equal(gpu_ctx, pm, f"view {it}")
+        pm.refine(it, pc, **kw_o); gpu_ctx.pm_refine(it, **kw_g)
+        _assert_state_equal(gpu_ctx, pm, f"refine {it}")
+
+
+@pytest.mark.parametrize("pairname", ["mid_pair", "odd_pair"])
+@pytest.mark.parametrize("name,scale_num,lam", MODES)
+@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
+def test_whole_pipeline_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam, sched):
+    """T3/T4: PatchMatch(3, plane_cost, false) + PlaneToDisp."""
+    pair = request.getfixturevalue(pairname)
+    pc, pm = _setup(gpu_ctx, pair, scale_num, lam)
+    pm.run(3, pc, False, seed=4242, schedule=sched, sum_order=po.SUM_LANE64, rb_rounds=1, rb_neighbours=4)
+    gpu_ctx.patchmatch(3, seed=4242, schedule=sched, rb_rounds=1, rb_neighbours=4, early_exit=1)
+    _assert_state_equal(gpu_ctx, pm, "final")
+    for v in (0, 1):
+        np.testing.assert_array_equal(gpu_ctx.disparity_u8(v, 4), pm.dis(v))
+        np.testing.assert_array_equal(gpu_ctx.disparity_f64(v), pm.disp_f64(v))
+
+
+def test_north_star_bar_vs_reference_order(gpu_ctx, mid_pair):
+    """>= 99.5 % of pixels within 0.5 px of the reference-order CPU path (raster sweep, serial
+    summation) on identical inputs and identical random numbers."""
+    for name, scale_num, lam in MODES:
+        pc, pm = _setup(gpu_ctx, mid_pair, scale_num, lam)
+        pm.run(3, pc, False, seed=31337, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+        gpu_ctx.patchmatch(3, seed=31337, schedule=po.SCHED_RASTER, early_exit=1)
+        for v in (0, 1):
+            d = np.abs(gpu_ctx.disparity_f64(v) - pm.disp_f64(v))
+            assert np.mean(d <= 0.5) >= 0.995, (name, v, float(np.mean(d <= 0.5)))
+
+
+def test_early_exit_is_result_preserving(gpu_ctx, small_pair):
+    _setup(gpu_ctx, small_pair, 5, 0.3)
+    out = []
+    for ee in (0, 1):
+        gpu_ctx.patchmatch(2, seed=5, schedule=po.SCHED_REDBLACK, early_exit=ee)
+        out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+    for v in (0, 1):
+        np.testing.assert_array_equal(out[0][v][0], out[1][v][0])
+        np.testing.assert_array_equal(out[0][v][1], out[1][v][1])
+
+
+def test_row_shared_rng_quirk(gpu_ctx, small_pair):
+    """USE_OMP quirk (cs_patchmatch.cc:129-131): every row draws the same stream."""
+    pc, pm = _setup(gpu_ctx, small_pair, 0, 0.0)
+    pm.init(pc, seed=9, rng_mode=po.RNG_ROW_SHARED, sum_order=po.SUM_LANE64)
+    gpu_ctx.pm_init(seed=9, rng_mode=1)
+    _assert_state_equal(gpu_ctx, pm, "init row-shared")
+    npar, _ = gpu_ctx.get_planes(0)
+    assert np.all(npar[:, :, :3] == npar[0:1, :, :3])  # identical normals down every column
+
+
+def test_set_planes_roundtrip_and_view_ties(gpu_ctx, small_pair):
+    """Collisions in view propagation: all source pixels of a row carry the same fronto-parallel plane,
+    so several of them hit one target with EQUAL cost; the first in traversal order must win."""
+    pc, pm = _setup(gpu_ctx, small_pair, 0, 0.0)
+    h, w, D = small_pair["h"], small_pair["w"], small_pair["max_dis"]
+    rng = np.random.default_rng(1)
+    for it in (0, 1):
+        for v in (0, 1):
+            P = pm.planes(v)
+            d = np.repeat(rng.integers(1, D - 1, (h, 1)).astype(np.float64), w, 1) + rng.choice([0.0, 0.3], (h, w))
+            P[..., 0:2] = 0.0; P[..., 2] = 1.0
+            P[..., 3] = np.arange(w)[None, :]; P[..., 4] = np.arange(h)[:, None]; P[..., 5] = d
+            P[..., 6:8] = 0.0; P[..., 8] = d
+            pm.min_cost(v)[...] = 1e9
+            gpu_ctx.set_planes(v, np.concatenate([P[..., 0:3], P[..., 6:9]], -1), pm.min_cost(v))
+        pm.view(it, pc, sum_order=po.SUM_LANE64); gpu_ctx.pm_view(it)
+        _assert_state_equal(gpu_ctx, pm, f"view ties iter {it}")
