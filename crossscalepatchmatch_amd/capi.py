@@ -14,11 +14,12 @@ RNG_PER_PIXEL, RNG_ROW_SHARED = 0, 1
 K_GRD, K_INIT, K_SPATIAL, K_VIEW, K_REFINE, K_MISC = range(6)
 K_NAMES = ["grd", "init", "spatial", "view", "refine", "misc"]
 MAX_LEVELS = 8
+OPT_GRD_VOLUMES = 1
 
 # every symbol include/cspm.h declares
 SYMBOLS = [
     "cspm_device_count", "cspm_create", "cspm_destroy", "cspm_last_error", "cspm_set_stream", "cspm_synchronize",
-    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_begin_cost", "cspm_upload_cost_slab",
+    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_set_option", "cspm_begin_cost", "cspm_upload_cost_slab",
     "cspm_finish_cost", "cspm_get_levels", "cspm_get_level_dims", "cspm_get_level_image", "cspm_get_cost_slab",
     "cspm_get_max_cost", "cspm_get_scale_weights", "cspm_grd_build_cv_host", "cspm_plane_cost_batch",
     "cspm_pm_default_params", "cspm_patchmatch", "cspm_pm_init", "cspm_pm_spatial", "cspm_pm_view", "cspm_pm_refine",
@@ -75,6 +76,7 @@ def load_library():
         "cspm_set_images": (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t]),
         "cspm_set_images_device": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]),
         "cspm_build_cost_grd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
+        "cspm_set_option": (C.c_int, [vp, C.c_int, C.c_longlong]),
         "cspm_begin_cost": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_upload_cost_slab": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, C.c_size_t]),
         "cspm_finish_cost": (C.c_int, [vp]),
@@ -163,7 +165,12 @@ class StereoContext:
     def synchronize(self):
         self._chk(self.L.cspm_synchronize(self.p))
 
-    def build_cost_grd(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):
+    def set_option(self, key, value):
+        self._chk(self.L.cspm_set_option(self.p, key, value))
+
+    def build_cost_grd(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False):
+        """volumes=False: fused on-the-fly GRD cells (default); True: materialised f64 cost volumes."""
+        self.set_option(OPT_GRD_VOLUMES, int(volumes))
         self._chk(self.L.cspm_build_cost_grd(self.p, max_dis, wnd_size, scale_num, reg_lambda))
 
     def begin_cost(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):

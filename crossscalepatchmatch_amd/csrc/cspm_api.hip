@@ -40,7 +40,9 @@ struct cspm_ctx {
   double scale_wgt[CSPM_MAX_LEVELS] = {0};
   double host_max_cost[2 * CSPM_MAX_LEVELS] = {0};
   std::vector<void *> cost_allocs;
-  double *d_lut = nullptr, *d_maxcost = nullptr;
+  double *d_lut = nullptr, *d_lut_a = nullptr, *d_maxcost = nullptr;
+  bool is_grd = false;           // cost built by cspm_build_cost_grd (gradients present)
+  long long opt_grd_volumes = 0; // CSPM_OPT_GRD_VOLUMES
   unsigned long long *d_maxkeys = nullptr;
   // plane field
   bool field_alloc = false;
@@ -135,6 +137,7 @@ inline unsigned eval_grid(long long items) {
   return (unsigned)nb;
 }
 inline unsigned ew_grid(long long n, int block = 256) { return (unsigned)((n + block - 1) / block); }
+inline unsigned stride_grid(long long n, int block = 256) { return (unsigned)std::min<long long>((n + block - 1) / block, 256 * 16); }
 
 void free_cost(cspm_ctx *c) {
   for (void *p : c->cost_allocs) (void)hipFree(p);
@@ -203,8 +206,9 @@ int scale_weights(int S, double lambda, double *w) {
   return 0;
 }
 
-// allocate pyramid images + volumes, fill Cost (everything except volume contents / max_cost)
-int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+// allocate the (padded) pyramid images and, when `with_vol`, the cost volumes; fill Cost (everything
+// except gradients / volume contents / max_cost)
+int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol) {
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
   if (max_dis < 1 || wnd_size < 1 || wnd_size > 127 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
     return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
@@ -216,6 +220,9 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   cd.n = 2 * cd.half + 1;
   cd.T = cd.n * cd.n;
   cd.groups = (cd.T + kWave - 1) / kWave;
+  cd.inv_n = 1.0f / (float)cd.n;
+  for (int t = 0; t < ((cd.groups + 3) / 4) * 256; ++t)  // the kernels' tap -> (dy,dx) formula must be exact
+    if ((int)(((float)t + 0.5f) * cd.inv_n) != t / cd.n) return fail(c, CSPM_ERR_ARG, "window too large for the float tap decode");
   c->max_dis = max_dis;
   c->wnd = wnd_size;
   int rc;
@@ -225,39 +232,56 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
     Level &L = cd.lv[s];
     L.W = W; L.H = H; L.D = D;
+    L.pad = D + 2;
+    L.Wp = W + 2 * L.pad;
     for (int v = 0; v < 2; ++v) {
       uint32_t *img;
-      double *vol;
-      if ((rc = dalloc(c, &img, (size_t)W * H, &c->cost_allocs))) return rc;
-      if ((rc = dalloc(c, &vol, (size_t)(D + 1) * W * H, &c->cost_allocs))) return rc;
-      L.img[v] = img;
-      L.vol[v] = vol;
+      if ((rc = dalloc(c, &img, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
+      L.pix[v] = img;
+      L.grd[v] = nullptr;
+      L.vol[v] = nullptr;
+      if (with_vol) {
+        double *vol;
+        if ((rc = dalloc(c, &vol, (size_t)(D + 1) * W * H, &c->cost_allocs))) return rc;
+        L.vol[v] = vol;
+      }
+      Timed t(c, CSPM_K_MISC, 0);
       if (s == 0) {
-        HIPCHK(c, hipMemcpyAsync(img, c->img0[v], sizeof(uint32_t) * (size_t)W * H, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_pad_u32, dim3(ew_grid((long long)L.Wp * H)), dim3(256), 0, c->stream, c->img0[v], W, H, L.Wp, L.pad, img);
       } else {
         const Level &P = cd.lv[s - 1];
-        Timed t(c, CSPM_K_MISC, 0);
-        hipLaunchKernelGGL(k_pyrdown, dim3(ew_grid((long long)W * H)), dim3(256), 0, c->stream, P.img[v], P.W, P.H, img, W, H);
+        hipLaunchKernelGGL(k_pyrdown, dim3(ew_grid((long long)L.Wp * H)), dim3(256), 0, c->stream, P.pix[v], P.W, P.H, P.Wp, P.pad,
+                           img, W, H, L.Wp, L.pad);
       }
     }
   }
-  // scale weights (pre_cs_pc.cc:86-109) and exp LUT (pre_cs_pc.cc:111-114)
+  // scale weights (pre_cs_pc.cc:86-109), exp LUT (pre_cs_pc.cc:111-114), GRD colour-term LUT (grd_cc.cpp:8-18)
   if (cd.cs) {
     if (scale_weights(cd.levels, reg_lambda, c->scale_wgt)) return fail(c, CSPM_ERR_ARG, "singular regularisation matrix");
   } else {
     c->scale_wgt[0] = 1.0;
   }
   for (int s = 0; s < cd.levels; ++s) cd.lv[s].wgt = c->scale_wgt[s];
-  double lut[kLutSize];
-  for (int i = 0; i < kLutSize; ++i) lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
-  if ((rc = dalloc(c, &c->d_lut, kLutSize, &c->cost_allocs))) return rc;
+  double lut[2 * kLutSize];
+  for (int i = 0; i < kLutSize; ++i) {
+    lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
+    double clrDiff = (double)i;          // sum of three |lC-rC|, an exact integer
+    clrDiff *= 0.3333333333;
+    clrDiff = clrDiff > 10.0 ? 10.0 : clrDiff;  // TAU_CLR
+    lut[kLutSize + i] = 0.1 * clrDiff;   // ALPHA * clrDiff
+  }
+  if ((rc = dalloc(c, &c->d_lut, 2 * kLutSize, &c->cost_allocs))) return rc;
+  c->d_lut_a = c->d_lut + kLutSize;
   if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
   if ((rc = dalloc(c, &c->d_maxkeys, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // lut[] is a stack buffer
   cd.lut = c->d_lut;
+  cd.lut_a = c->d_lut_a;
   cd.max_cost = c->d_maxcost;
+  cd.fused = 0;
+  c->is_grd = false;
   c->cost_alloc = true;
   return CSPM_OK;
 }
@@ -318,10 +342,12 @@ int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
   return ensure_field(c);
 }
 
-#define LAUNCH_CS(kern, grid, block, shmem, ...)                                                   \
-  do {                                                                                             \
-    if (c->cost.cs) hipLaunchKernelGGL(kern<true>, grid, block, shmem, c->stream, __VA_ARGS__);    \
-    else hipLaunchKernelGGL(kern<false>, grid, block, shmem, c->stream, __VA_ARGS__);              \
+#define LAUNCH_CS(kern, grid, block, shmem, ...)                                                          \
+  do {                                                                                                    \
+    if (c->cost.cs && c->cost.fused) hipLaunchKernelGGL((kern<true, true>), grid, block, shmem, c->stream, __VA_ARGS__);        \
+    else if (c->cost.cs) hipLaunchKernelGGL((kern<true, false>), grid, block, shmem, c->stream, __VA_ARGS__);                  \
+    else if (c->cost.fused) hipLaunchKernelGGL((kern<false, true>), grid, block, shmem, c->stream, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((kern<false, false>), grid, block, shmem, c->stream, __VA_ARGS__);                                 \
   } while (0)
 
 int do_init(cspm_ctx *c, const cspm_pm_params *p) {
@@ -350,7 +376,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
       const long long items = 2LL * (ys_hi - ys_lo + 1);
       Timed t(c, CSPM_K_SPATIAL, items * 2);
-      LAUNCH_CS(k_spatial_diag, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, k, inc);
+      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(kDiagBlock), 0, c->cost, pm, k, inc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -483,7 +509,7 @@ static int set_images_impl(cspm_ctx *c, const void *l, const void *r, int w, int
       d_src = tmp;
     }
     Timed t(c, CSPM_K_MISC, 0);
-    hipLaunchKernelGGL(k_pack_bgr, dim3(ew_grid((long long)w * h)), dim3(256), 0, c->stream, d_src, stride, w, h, c->img0[v]);
+    hipLaunchKernelGGL(k_pack_bgr, dim3(ew_grid((long long)w * h)), dim3(256), 0, c->stream, d_src, stride, w, h, w, 0, c->img0[v]);
     if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   if (tmp) (void)hipFree(tmp);
@@ -498,40 +524,53 @@ int cspm_set_images_device(cspm_ctx *c, const void *l, const void *r, int w, int
   return set_images_impl(c, l, r, w, h, stride, true);
 }
 
+int cspm_set_option(cspm_ctx *c, int key, long long value) {
+  if (!c) return CSPM_ERR_ARG;
+  switch (key) {
+    case CSPM_OPT_GRD_VOLUMES: c->opt_grd_volumes = value ? 1 : 0; return CSPM_OK;
+    default: return fail(c, CSPM_ERR_ARG, "unknown option");
+  }
+}
+
 int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda);
+  const bool with_vol = c->opt_grd_volumes != 0;
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol);
   if (rc) return rc;
   Cost &cd = c->cost;
-  // gradients of both views per level (grd_cc.cpp:70-77), then both volumes (pre_cs_pc.cc:57-84)
-  std::vector<void *> tmp;
+  // gradients of both views per level (grd_cc.cpp:70-77); then the GRD cells of both views
+  // (pre_cs_pc.cc:57-84): stored as volumes when CSPM_OPT_GRD_VOLUMES, otherwise only their max is
+  // reduced (pre_cs_pc.cc:75-82) and the PatchMatch kernels recompute cells on the fly.
   for (int s = 0; s < cd.levels; ++s) {
-    const Level &L = cd.lv[s];
-    const long long px = (long long)L.W * L.H;
-    double *g[2];
+    Level &L = cd.lv[s];
+    const long long ppx = (long long)L.Wp * L.H;
     for (int v = 0; v < 2; ++v) {
-      if ((rc = dalloc(c, &g[v], (size_t)px, &tmp))) return rc;
+      double *g;
+      if ((rc = dalloc(c, &g, (size_t)ppx, &c->cost_allocs))) return rc;
+      L.grd[v] = g;
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.img[v]}, L.W, L.H, g[v]);
+      hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H,
+                         L.Wp, L.pad, g);
     }
-    const long long cells = px * (L.D + 1);
+    const long long cells = (long long)L.W * L.H * (L.D + 1);
     for (int v = 0; v < 2; ++v) {
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(ew_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.img[0]}, SrcU32{L.img[1]},
-                         g[0], g[1], L.W, L.H, L.D + 1, v, (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+      hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(stride_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
+                         SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, 0, L.D + 1, v,
+                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
     }
   }
   HIPCHK(c, hipGetLastError());
-  rc = finish_cost(c);
-  for (void *p : tmp) (void)hipFree(p);
-  return rc;
+  cd.fused = with_vol ? 0 : 1;
+  c->is_grd = true;
+  return finish_cost(c);
 }
 
 int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda);
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, true);
   if (rc) return rc;
   for (int s = 0; s < c->cost.levels; ++s)
     for (int v = 0; v < 2; ++v) {
@@ -543,7 +582,7 @@ int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, doubl
 
 int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double *slab, size_t stride_elems) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   if (view < 0 || view > 1 || level < 0 || level >= c->cost.levels || !slab) return fail(c, CSPM_ERR_ARG, "bad view/level/slab");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D || stride_elems < (size_t)L.W) return fail(c, CSPM_ERR_ARG, "bad slab index or stride");
@@ -557,7 +596,7 @@ int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double 
 
 int cspm_finish_cost(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
   for (int s = 0; s < c->cost.levels; ++s)
     for (int v = 0; v < 2; ++v) {
@@ -587,7 +626,7 @@ int cspm_get_level_image(cspm_ctx *c, int view, int level, uint8_t *out) {
   const size_t px = (size_t)L.W * L.H;
   uint8_t *tmp;
   HIPCHK(c, hipMalloc((void **)&tmp, px * 3));
-  hipLaunchKernelGGL(k_unpack_bgr, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, L.img[view], L.W, L.H, tmp);
+  hipLaunchKernelGGL(k_unpack_bgr, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, L.pix[view], L.W, L.H, L.Wp, L.pad, tmp);
   HIPCHK(c, hipMemcpyAsync(out, tmp, px * 3, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(tmp);
@@ -599,8 +638,22 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
   if (!c->cost_alloc || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_ARG, "bad view/level");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D) return fail(c, CSPM_ERR_ARG, "bad slab index");
-  HIPCHK(c, hipMemcpyAsync(out, L.vol[view] + (size_t)d * L.W * L.H, sizeof(double) * (size_t)L.W * L.H, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t px = (size_t)L.W * L.H;
+  if (L.vol[view]) {
+    HIPCHK(c, hipMemcpyAsync(out, L.vol[view] + (size_t)d * px, sizeof(double) * px, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CSPM_OK;
+  }
+  // fused GRD cost: materialise the requested slab with the volume kernel
+  double *tmp;
+  HIPCHK(c, hipMalloc((void **)&tmp, sizeof(double) * px));
+  hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
+                     SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, d, 1, view, tmp,
+                     (unsigned long long *)nullptr);
+  hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * px, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail(c, CSPM_ERR_HIP, hipGetErrorString(e));
   return CSPM_OK;
 }
 
@@ -639,10 +692,10 @@ int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
       hipMemcpyAsync(dr, r_rgb, sizeof(double) * px * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
       hipMemsetAsync(key, 0, sizeof *key, c->stream) != hipSuccess)
     return done(fail(c, CSPM_ERR_HIP, "upload failed"));
-  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dl}, w, h, gl);
-  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dr}, w, h, gr);
-  hipLaunchKernelGGL(k_grd_volume<SrcF64>, dim3(ew_grid((long long)px * maxDis)), dim3(256), 0, c->stream, SrcF64{dl}, SrcF64{dr}, gl, gr,
-                     w, h, maxDis, right_view, vol, key);
+  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dl, w}, w, h, w, 0, gl);
+  hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dr, w}, w, h, w, 0, gr);
+  hipLaunchKernelGGL(k_grd_volume<SrcF64>, dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, SrcF64{dl, w}, SrcF64{dr, w},
+                     gl, gr, w, 0, w, h, 0, maxDis, right_view, vol, key);
   if (hipMemcpyAsync(vol_out, vol, sizeof(double) * px * maxDis, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)
     return done(fail(c, CSPM_ERR_HIP, "GRD volume kernel failed"));

@@ -16,25 +16,34 @@ constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_
 constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
 constexpr int kWave = 64;
 constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup
-constexpr int kCheckEvery = 4;             // early-exit checkpoint every 4 tap groups (and at level end)
+constexpr int kDiagBlock = 512;            // raster-sweep kernel: 8 waves cooperate on one pixel (2 candidates x 4 slot blocks)
+constexpr uint32_t kBorderPix = 0x00030303u;  // BORDER_THRES in B, G and R (cc/grd_cc.h:6)
 
 // One pyramid level of one PreSSPC/PreCSPC object (pre_cs_pc.h:41-56).
+// Images are stored PADDED: row stride Wp = W + 2*pad, image column x at index pad + x, pad = D + 2.
+// Pad cells hold the GRD border constant (BORDER_THRES = 3 for every channel and for the gradient,
+// cc/grd_cc.h:6), so the fused cost needs no border branch (cc/grd_cc.cpp:88-100, 134-147).
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
-  const uint32_t *img[2]; // packed B | G<<8 | R<<16 (byte 3 = 0), row-major H*W
-  const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major
+  int Wp, pad;
+  const uint32_t *pix[2]; // packed B | G<<8 | R<<16 (byte 3 = 0), H rows of Wp
+  const double *grd[2];   // x-gradient of the f32 gray image (grd_cc.cpp:70-77), H rows of Wp; GRD only
+  const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; may be null when fused
   double wgt;             // scale_wgt_[s]
 };
 
 struct Cost {
   int cs;      // 0: PreSSPC::GetPlaneCost, 1: PreCSPC::GetPlaneCost
+  int fused;   // 1: GRD cell costs are computed on the fly from pix/grd, 0: read from vol
   int levels;
   int half;    // half_wnd_
   int n;       // 2*half+1
   int T;       // n*n taps
   int groups;  // ceil(T/64)
+  float inv_n; // 1.0f/n: dy = (int)(((float)t + 0.5f) * inv_n), verified exhaustively on the host
   int early_ok;           // all scale weights and max_costs are >= 0
   const double *lut;      // lookup_exp_[i] = exp(-i/10), host-computed, kLutSize entries
+  const double *lut_a;    // GRD colour term ALPHA*min(i*0.3333333333, TAU_CLR) (grd_cc.cpp:8-18), kLutSize entries
   const double *max_cost; // device, [view*CSPM_MAX_LEVELS + level]
   Level lv[CSPM_MAX_LEVELS];
 };
@@ -105,8 +114,8 @@ struct Rng {
   __device__ __forceinline__ double uniform(uint32_t draw, double a, double b) const { return u01(draw) * (b - a) + a; }
 };
 
-// sum over the 64 lanes: xor butterfly with ascending offsets 1,2,4,8,16,32 (the LANE64 order of the
-// oracle).  Every lane ends with the same bits because a+b == b+a.
+// sum over the 64 lanes: xor butterfly with ascending offsets 1,2,4,8,16,32 (last stage of the
+// SLOT256 order of the oracle).  Every lane ends with the same bits because a+b == b+a.
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);

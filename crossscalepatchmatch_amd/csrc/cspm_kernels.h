@@ -1,12 +1,24 @@
 // cspm_kernels.h -- the HIP kernels of the PatchMatch-stereo hot path (gfx950, wave64).
 //
-// Mapping: ONE WAVEFRONT EVALUATES ONE CANDIDATE PLANE.  The 64 lanes stride over the linearised
-// (2*half+1)^2 support window (tap t -> lane t%64), so the plane parameters, the centre pixel and all
-// branch decisions (early exit, accept/reject) are wave-uniform, and the guide-image / cost-volume
-// addresses of a wave are runs along image rows of ONE plane: coalesced regardless of how incoherent
-// the plane field of neighbouring pixels is (random init, early refinement steps).
-// A workgroup is 4 waves = 4 consecutive candidates; blockIdx is remapped so that each XCD (block b
-// runs on XCD b%8) walks one contiguous band of the image and keeps its cost-volume rows in its own L2.
+// Mapping: ONE WAVEFRONT EVALUATES ONE CANDIDATE PLANE (k_init / k_refine / k_spatial_rb / k_view_eval /
+// k_cost_batch).  The 64 lanes stride over the linearised (2*half+1)^2 support window (tap t -> lane
+// t%64), so the plane parameters, the centre pixel and all branch decisions (early exit, accept/reject)
+// are wave-uniform, and the image / cost-volume addresses of a wave are runs along image rows of ONE
+// plane: coalesced however incoherent the plane field of neighbouring pixels is (random init, early
+// refinement steps).  A workgroup is 4 waves = 4 consecutive candidates; blockIdx is remapped so that
+// each XCD (block b runs on XCD b%8) walks one contiguous band of the image and keeps that band's image
+// rows in its own L2.  The reference's raster sweep is run as anti-diagonals with 8 cooperating waves
+// per pixel (k_spatial_diag), because a diagonal has only <= min(W,H) independent pixels.
+//
+// Cell costs come from one of two sources, selected at compile time:
+//   FUSED = true : GRD cell cost computed on the fly from the padded images + gradients (bit-identical
+//                  to reading GrdCC's volume, cc/grd_cc.cpp:4-35,60-154); nothing but ~12 B/pixel per
+//                  view and level is ever read, so the working set stays in L2 / Infinity Cache.
+//   FUSED = false: cost volumes in HBM (any CCMethod plugin; what the reference's PreSSPC/PreCSPC do).
+//
+// Summation order ("SLOT256", mirrored by the oracle): tap t is accumulated in t order into slot
+// t%256 (= accumulator (t/64)%4 of lane t%64); slots are reduced as (p0+p1)+(p2+p3) per lane, then an
+// xor butterfly with offsets 1..32.
 #pragma once
 #include "cspm_device.h"
 
@@ -17,50 +29,107 @@ namespace cspm {
 // ------------------------------------------------------------------------------------------------
 // IPlaneCost::GetPlaneCost  (PreSSPC: pre_ss_pc.cc:74-118, PreCSPC: pre_cs_pc.cc:133-188)
 // ------------------------------------------------------------------------------------------------
+struct Luts {
+  const double *w;  // exp(-i/10)                        (pre_cs_pc.cc:111-114)
+  const double *a;  // ALPHA*min(i*0.3333333333,TAU_CLR)  (grd_cc.cpp:8-18), fused path only
+};
 
-// One level: sum over the window of  w(p,q) * lerp(cost_vol[floor], cost_vol[ceil])  (pre_cs_pc.cc:151-181).
-// Returns the level sum (identical in all lanes) or -1.0 when base + partial*mul >= thresh was proven.
-__device__ __forceinline__ double level_cost(const Cost &cd, const Level &L, const double *s_lut, int view, int s,
-                                             int cx, int cy, double a, double b, double c, double base, double mul,
-                                             double thresh, bool use_thresh, int lane, int dy0, int dx0) {
-  const int W = L.W, H = L.H, half = cd.half, n = cd.n, T = cd.T, groups = cd.groups;
-  const double Dd = (double)L.D;
-  const double maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
-  const uint32_t *__restrict__ img = L.img[view];
-  const double *__restrict__ vol = L.vol[view];
-  const size_t slab = (size_t)W * (size_t)H;
-  const uint32_t Ip = img[(size_t)cy * W + cx];
-  const int q64 = kWave / n, r64 = kWave % n;
-  double part = 0.0;
-  int t = lane, dy = dy0, dx = dx0;
-  for (int g = 0; g < groups; ++g) {
-    const int qy = cy + dy - half, qx = cx + dx - half;
-    const bool ok = (t < T) && ((unsigned)qy < (unsigned)H) && ((unsigned)qx < (unsigned)W);
-    if (ok) {
-      const size_t o = (size_t)qy * W + qx;
-      const uint32_t Iq = img[o];
-      const int sum = (int)__builtin_amdgcn_sad_u8(Ip, Iq, 0u);  // |dB|+|dG|+|dR| (pre_cs_pc.cc:161-163)
-      const double wgt = s_lut[sum];
-      const double q_disp_y = b * (double)qy + c;                 // :155
-      const double q_disp = a * (double)qx + q_disp_y;            // :165
-      // static_cast<int>(q_disp) in 1..D-1  <=>  1.0 <= q_disp < D ; NaN / out of range -> invalid (:166-169)
-      const bool valid = (q_disp >= 1.0) && (q_disp < Dd);
-      double tmp = maxc;
-      if (valid) {
-        const int f = (int)q_disp;
-        const double floor_wgt = (double)(f + 1) - q_disp;       // :171-172
-        const double *c0 = vol + (size_t)f * slab + o;
-        tmp = floor_wgt * c0[0] + (1 - floor_wgt) * c0[slab];    // :173-175
-      }
-      part += wgt * tmp;                                          // :176 / :169
-    }
-    t += kWave;
-    dx += r64;
-    dy += q64;
-    if (dx >= n) { dx -= n; ++dy; }
-    const bool last = (g == groups - 1);
-    if (last || (use_thresh && (g % kCheckEvery) == kCheckEvery - 1)) {
-      const double tot = wave_sum(part);
+// everything one level needs, wave-uniform
+struct LevelArgs {
+  int W, H, Wp, pad, cx, cy, dir;
+  double Dd, maxc, a, b, c;
+  const uint32_t *pix, *opix;
+  const double *grd, *ogrd, *vol;
+  size_t slab;
+  uint32_t Ip;
+};
+
+template <bool FUSED>
+__device__ __forceinline__ LevelArgs make_level(const Cost &cd, int s, int view, int cx, int cy, double a, double b, double c) {
+  const Level &L = cd.lv[s];
+  LevelArgs A;
+  A.W = L.W; A.H = L.H; A.Wp = L.Wp; A.pad = L.pad; A.cx = cx; A.cy = cy;
+  A.dir = view == 0 ? -1 : 1;  // left view looks at x-d in the right image, right view at x+d in the left
+  A.Dd = (double)L.D;
+  A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
+  A.a = a; A.b = b; A.c = c;
+  A.pix = L.pix[view]; A.opix = L.pix[1 - view];
+  A.grd = L.grd[view]; A.ogrd = L.grd[1 - view];
+  A.vol = L.vol[view];
+  A.slab = (size_t)L.W * (size_t)L.H;
+  A.Ip = A.pix[(size_t)cy * L.Wp + L.pad + cx];
+  return A;
+}
+
+// myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
+// arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
+// TAU_CLR) is a table of the SAD.
+__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, uint32_t Io, double Go) {
+  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, Io, 0u);
+  double grdDiff = fabs(Gq - Go);
+  grdDiff = grdDiff > 2.0 ? 2.0 : grdDiff;  // TAU_GRD
+  return lut.a[sad] + (1 - 0.1) * grdDiff;  // ALPHA*clrDiff + (1-ALPHA)*grdDiff
+}
+
+// One window tap t (pre_cs_pc.cc:157-179): returns wgt * interpolated cell cost, or +0.0 for taps
+// outside the window / image.  Branch-free: masked lanes read the centre pixel.
+template <bool FUSED>
+__device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
+  // NB: every `c ? x : y` below has plain locals on both sides.  clang emits a real branch for a
+  // conditional operator with a member access in an arm, and LLVM then sinks all loads of this tap
+  // into that branch, which serialises the four taps of a round behind s_waitcnt vmcnt(0).
+  const int ccx = A.cx, ccy = A.cy;
+  const double maxc = A.maxc, zero = 0.0, one = 1.0;
+  const int dy = (int)(((float)t + 0.5f) * cd.inv_n);
+  const int dx = t - dy * cd.n;
+  const int qy0 = ccy + dy - cd.half, qx0 = ccx + dx - cd.half;
+  const bool ok = (t < cd.T) & ((unsigned)qy0 < (unsigned)A.H) & ((unsigned)qx0 < (unsigned)A.W);
+  const int qy = ok ? qy0 : ccy, qx = ok ? qx0 : ccx;
+  const size_t row = (size_t)qy * A.Wp + A.pad;
+  const uint32_t Iq = A.pix[row + qx];
+  const int sum = (int)__builtin_amdgcn_sad_u8(A.Ip, Iq, 0u);  // |dB|+|dG|+|dR|  (:161-163)
+  const double wgt = lut.w[sum];                               // :164
+  const double q_disp_y = A.b * (double)qy + A.c;              // :155
+  const double q_disp = A.a * (double)qx + q_disp_y;           // :165
+  // static_cast<int>(q_disp) in [1, D-1]  <=>  1.0 <= q_disp < D; NaN / out of int range -> the
+  // "impossible disparity" branch (:166-169), as x86 cvttsd2si (INT_MIN) takes it.
+  const bool valid = (q_disp >= 1.0) & (q_disp < A.Dd);
+  const int f = (int)(valid ? q_disp : one);
+  const double floor_wgt = (double)(f + 1) - q_disp;           // :171-172
+  double c0, c1;
+  if (FUSED) {
+    const double Gq = A.grd[row + qx];
+    const size_t of = row + (qx + A.dir * f), oc = of + A.dir;
+    c0 = grd_cell(lut, Iq, Gq, A.opix[of], A.ogrd[of]);
+    c1 = grd_cell(lut, Iq, Gq, A.opix[oc], A.ogrd[oc]);
+  } else {
+    const double *p = A.vol + (size_t)f * A.slab + (size_t)qy * A.W + qx;
+    c0 = p[0];
+    c1 = p[A.slab];
+  }
+  double tmp = floor_wgt * c0 + (1 - floor_wgt) * c1;          // :173-175
+  tmp = valid ? tmp : maxc;                                    // :169
+  const double term = wgt * tmp;                               // :176
+  return ok ? term : zero;
+}
+
+// One level, one wave: returns the level sum (identical in all lanes) or -1.0 once
+// base + partial*mul >= thresh is proven (all terms are >= 0: monotone, so the candidate is rejected).
+template <bool FUSED>
+__device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A, const Luts &lut, double base, double mul,
+                                             double thresh, bool use_thresh, int lane) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int rounds = (cd.groups + 3) / 4;
+  for (int i = 0; i < rounds; ++i) {
+    const int t = i * 256 + lane;
+    const double t0 = tap_term<FUSED>(cd, A, lut, t);
+    const double t1 = tap_term<FUSED>(cd, A, lut, t + 64);
+    const double t2 = tap_term<FUSED>(cd, A, lut, t + 128);
+    const double t3 = tap_term<FUSED>(cd, A, lut, t + 192);
+    a0 += t0; a1 += t1; a2 += t2; a3 += t3;
+    const bool last = (i == rounds - 1);
+    if (last || use_thresh) {
+      const double tot = wave_sum((a0 + a1) + (a2 + a3));
       if (use_thresh && base + tot * mul >= thresh) return -1.0;
       if (last) return tot;
     }
@@ -70,13 +139,13 @@ __device__ __forceinline__ double level_cost(const Cost &cd, const Level &L, con
 
 // Aggregated plane cost at (x,y); +inf when the candidate is proven not to beat `thresh`.
 // (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param().
-template <bool CS>
-__device__ __forceinline__ double eval_plane(const Cost &cd, const double *s_lut, int view, int x, int y, double nx,
-                                             double ny, double nz, double pa, double pb, double pc, double thresh,
-                                             bool use_thresh, int lane) {
-  const int dy0 = lane / cd.n, dx0 = lane % cd.n;
+template <bool CS, bool FUSED>
+__device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, int view, int x, int y, double nx, double ny,
+                                             double nz, double pa, double pb, double pc, double thresh, bool use_thresh,
+                                             int lane) {
   if (!CS) {
-    const double r = level_cost(cd, cd.lv[0], s_lut, view, 0, x, y, pa, pb, pc, 0.0, 1.0, thresh, use_thresh, lane, dy0, dx0);
+    const LevelArgs A = make_level<FUSED>(cd, 0, view, x, y, pa, pb, pc);
+    const double r = level_cost<FUSED>(cd, A, lut, 0.0, 1.0, thresh, use_thresh, lane);
     return r < 0.0 ? __builtin_inf() : r;
   }
   double cost = 0.0;
@@ -86,7 +155,8 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const double *s_lut
     double a, b, c;
     plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
     const double wgt = cd.lv[s].wgt;
-    const double sc = level_cost(cd, cd.lv[s], s_lut, view, s, cur_x, cur_y, a, b, c, cost, wgt, thresh, use_thresh, lane, dy0, dx0);
+    const LevelArgs A = make_level<FUSED>(cd, s, view, cur_x, cur_y, a, b, c);
+    const double sc = level_cost<FUSED>(cd, A, lut, cost, wgt, thresh, use_thresh, lane);
     if (sc < 0.0) return __builtin_inf();
     cost += sc * wgt;  // :182
     cur_y /= 2;        // :183-185
@@ -96,46 +166,62 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const double *s_lut
   return cost;
 }
 
-__device__ __forceinline__ void load_lut(const Cost &cd, double *s_lut) {
-  for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) s_lut[i] = cd.lut[i];
+struct LutMem {
+  double w[kLutSize];
+  double a[kLutSize];
+};
+__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem &m) {
+  for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) {
+    m.w[i] = cd.lut[i];
+    m.a[i] = cd.lut_a[i];
+  }
   __syncthreads();
+  return Luts{m.w, m.a};
 }
 
 // Work item (candidate) index of this wave.  Blocks are dealt round-robin to the 8 XCDs; give XCD k
 // the k-th contiguous eighth of the index space.
+__device__ __forceinline__ long long xcd_block() {
+  const long long per = (long long)gridDim.x / 8;  // gridDim.x is a multiple of 8
+  return (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+}
 __device__ __forceinline__ long long wave_item(long long n_items) {
-  const long long nb = (long long)gridDim.x;  // multiple of 8
-  const long long per = nb / 8;
-  const long long b = (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long e = b * (kEvalBlock / kWave) + wave;
+  const long long e = xcd_block() * (kEvalBlock / kWave) + wave;
   return e < n_items ? e : -1;
+}
+
+__device__ __forceinline__ void store_plane(const Field &f, long long i, double nx, double ny, double nz, double a, double b,
+                                            double c, double cost) {
+  f.nx[i] = nx; f.ny[i] = ny; f.nz[i] = nz;
+  f.a[i] = a; f.b[i] = b; f.c[i] = c;
+  f.cost[i] = cost;
 }
 
 // ------------------------------------------------------------------------------------------------
 // cspm_plane_cost_batch: batched GetPlaneCost on explicit (x,y,plane) tuples -- the parity hook.
 // ------------------------------------------------------------------------------------------------
-template <bool CS>
+template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, int n, const int *__restrict__ xy,
                                                            const double *__restrict__ np, double *__restrict__ out) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+  __shared__ LutMem s_lut;
+  const Luts lut = load_luts(cd, s_lut);
   const long long e = wave_item(n);
   if (e < 0) return;
   const int lane = threadIdx.x & 63;
   const int x = xy[2 * e], y = xy[2 * e + 1];
   const double *p = np + 6 * e;
-  const double c = eval_plane<CS>(cd, s_lut, view, x, y, p[0], p[1], p[2], p[3], p[4], p[5], kDoubleMax, false, lane);
+  const double c = eval_plane<CS, FUSED>(cd, lut, view, x, y, p[0], p[1], p[2], p[3], p[4], p[5], kDoubleMax, false, lane);
   if (lane == 0) out[e] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
 // CSPatchMatch::InitRandomPlane  (cs_patchmatch.cc:115-148)
 // ------------------------------------------------------------------------------------------------
-template <bool CS>
+template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+  __shared__ LutMem s_lut;
+  const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long e = wave_item(2 * npix);
   if (e < 0) return;
@@ -161,22 +247,17 @@ __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
   const double nx = r0 * inv, ny = r1 * inv, nz = r2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)y, rand_dis, a, b, c);  // :141-142
-  const double cost = eval_plane<CS>(cd, s_lut, v, x, y, nx, ny, nz, a, b, c, kDoubleMax, false, lane);  // :143-144
-  if (lane == 0) {
-    const Field &f = pm.f[v];
-    f.nx[i] = nx; f.ny[i] = ny; f.nz[i] = nz;
-    f.a[i] = a; f.b[i] = b; f.c[i] = c;
-    f.cost[i] = cost;
-  }
+  const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, nx, ny, nz, a, b, c, kDoubleMax, false, lane);  // :143-144
+  if (lane == 0) store_plane(pm.f[v], i, nx, ny, nz, a, b, c, cost);
 }
 
 // ------------------------------------------------------------------------------------------------
 // CSPatchMatch::PlaneRefinement, one halving step  (cs_patchmatch.cc:303-344)
 // ------------------------------------------------------------------------------------------------
-template <bool CS>
+template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter, int step, double z_iter, double n_iter) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+  __shared__ LutMem s_lut;
+  const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long e = wave_item(2 * npix);
   if (e < 0) return;
@@ -200,38 +281,19 @@ __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter,
   const double nx = d0 * inv, ny = d1 * inv, nz = d2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)y, pz, a, b, c);                // :330
-  const double cost = eval_plane<CS>(cd, s_lut, v, x, y, nx, ny, nz, a, b, c, cur_min, pm.use_thresh != 0, lane);
-  if (cost < cur_min && lane == 0) {                                         // :335-338
-    f.nx[i] = nx; f.ny[i] = ny; f.nz[i] = nz;
-    f.a[i] = a; f.b[i] = b; f.c[i] = c;
-    f.cost[i] = cost;
-  }
+  const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, nx, ny, nz, a, b, c, cur_min, pm.use_thresh != 0, lane);
+  if (cost < cur_min && lane == 0) store_plane(f, i, nx, ny, nz, a, b, c, cost);  // :335-338
 }
 
 // ------------------------------------------------------------------------------------------------
-// CSPatchMatch::SpatialPropagation.
-// k_spatial_rb: red-black half-step (fast path).  k_spatial_diag: one anti-diagonal of the reference's
-// in-place raster sweep (cs_patchmatch.cc:163-216); pixels on a diagonal are mutually independent.
+// CSPatchMatch::SpatialPropagation, red-black half-step (fast, lower-quality schedule).
 // ------------------------------------------------------------------------------------------------
 struct Cand { double nx, ny, nz, a, b, c; };
 
-template <bool CS>
-__device__ __forceinline__ void try_neighbour(const Cost &cd, const double *s_lut, const Field &f, int v, int x, int y,
-                                              long long j, Cand &best, double &best_cost, bool &changed, bool use_thresh,
-                                              int lane) {
-  const double nx = f.nx[j], ny = f.ny[j], nz = f.nz[j], a = f.a[j], b = f.b[j], c = f.c[j];
-  const double cost = eval_plane<CS>(cd, s_lut, v, x, y, nx, ny, nz, a, b, c, best_cost, use_thresh, lane);
-  if (cost < best_cost) {
-    best_cost = cost;
-    best = Cand{nx, ny, nz, a, b, c};
-    changed = true;
-  }
-}
-
-template <bool CS>
+template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int colour, int inc, int nb) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+  __shared__ LutMem s_lut;
+  const Luts lut = load_luts(cd, s_lut);
   const int halfW = (pm.W + 1) / 2;
   const long long per_view = (long long)halfW * pm.H;
   const long long e = wave_item(2 * per_view);
@@ -250,41 +312,81 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
   const int nxs[4] = {x - inc, x, x + inc, x}, nys[4] = {y, y - inc, y, y + inc};
   for (int k = 0; k < nb; ++k) {
     if (nxs[k] < 0 || nxs[k] >= pm.W || nys[k] < 0 || nys[k] >= pm.H) continue;
-    try_neighbour<CS>(cd, s_lut, f, v, x, y, (long long)nys[k] * pm.W + nxs[k], best, best_cost, changed, pm.use_thresh != 0, lane);
+    const long long j = (long long)nys[k] * pm.W + nxs[k];
+    const Cand cand{f.nx[j], f.ny[j], f.nz[j], f.a[j], f.b[j], f.c[j]};
+    const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, cand.nx, cand.ny, cand.nz, cand.a, cand.b, cand.c, best_cost,
+                                              pm.use_thresh != 0, lane);
+    if (cost < best_cost) { best_cost = cost; best = cand; changed = true; }
   }
-  if (changed && lane == 0) {
-    f.nx[i] = best.nx; f.ny[i] = best.ny; f.nz[i] = best.nz;
-    f.a[i] = best.a; f.b[i] = best.b; f.c[i] = best.c;
-    f.cost[i] = best_cost;
-  }
+  if (changed && lane == 0) store_plane(f, i, best.nx, best.ny, best.nz, best.a, best.b, best.c, best_cost);
 }
 
-// diagonal k of the sweep: sweep coordinates (xs,ys), xs+ys == k; image x = inc>0 ? xs : W-1-xs.
-// A pixel first tries the plane of its x-predecessor, then of its y-predecessor (:198-212); the first
-// sweep row has only the former (:178-186), the first sweep column only the latter (:189-195).
-template <bool CS>
-__global__ __launch_bounds__(kEvalBlock) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+// ------------------------------------------------------------------------------------------------
+// CSPatchMatch::SpatialPropagation in the reference's order (cs_patchmatch.cc:163-216): the in-place
+// raster sweep makes pixel (x,y) depend on (x-inc,y) and (x,y-inc) only, so all pixels of one
+// anti-diagonal are independent.  One launch per diagonal k (sweep coordinates xs+ys == k, image
+// x = inc>0 ? xs : W-1-xs); one 8-wave workgroup per pixel: waves 0-3 evaluate the x-predecessor's
+// plane, waves 4-7 the y-predecessor's, each wave one of the four SLOT256 accumulator blocks of every
+// level.  A pixel tries the x-predecessor first, then the y-predecessor against the updated minimum
+// (:198-212); the first sweep row has only the former (:178-186), the first column only the latter
+// (:189-195).  No early exit: both candidate costs are needed in full when accepted.
+// ------------------------------------------------------------------------------------------------
+template <bool CS, bool FUSED>
+__global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
+  __shared__ LutMem s_lut;
+  __shared__ double s_part[2][CSPM_MAX_LEVELS][4][kWave];
+  __shared__ double s_cost[2];
+  const Luts lut = load_luts(cd, s_lut);
   const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
   const int cnt = ys_hi - ys_lo + 1;
-  const long long e = wave_item(2LL * cnt);
-  if (e < 0) return;
-  const int lane = threadIdx.x & 63;
-  const int v = (int)(e / cnt);
-  const int ys = ys_lo + (int)(e - (long long)v * cnt), xs = k - ys;
+  const int b = (int)blockIdx.x;
+  const int v = b / cnt;  // grid = 2*cnt
+  const int ys = ys_lo + (b - v * cnt), xs = k - ys;
   const int x = inc > 0 ? xs : pm.W - 1 - xs, y = inc > 0 ? ys : pm.H - 1 - ys;
   const Field &f = pm.f[v];
   const long long i = (long long)y * pm.W + x;
-  Cand best{};
-  double best_cost = f.cost[i];
-  bool changed = false;
-  if (xs > 0) try_neighbour<CS>(cd, s_lut, f, v, x, y, i - inc, best, best_cost, changed, pm.use_thresh != 0, lane);
-  if (ys > 0) try_neighbour<CS>(cd, s_lut, f, v, x, y, i - (long long)inc * pm.W, best, best_cost, changed, pm.use_thresh != 0, lane);
-  if (changed && lane == 0) {
-    f.nx[i] = best.nx; f.ny[i] = best.ny; f.nz[i] = best.nz;
-    f.a[i] = best.a; f.b[i] = best.b; f.c[i] = best.c;
-    f.cost[i] = best_cost;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int cand = wave >> 2, blk = wave & 3;
+  const bool have = cand == 0 ? (xs > 0) : (ys > 0);
+  const long long j = cand == 0 ? i - inc : i - (long long)inc * pm.W;
+  const int levels = CS ? cd.levels : 1;
+  Cand c{};
+  if (have) {
+    c = Cand{f.nx[j], f.ny[j], f.nz[j], f.a[j], f.b[j], f.c[j]};
+    double cur_disp = c.a * (double)x + c.b * (double)y + c.c;  // pre_cs_pc.cc:139-140
+    int cur_x = x, cur_y = y;
+    for (int s = 0; s < levels; ++s) {
+      double pa = c.a, pb = c.b, pc = c.c;
+      if (CS) plane_param(c.nx, c.ny, c.nz, (double)cur_x, (double)cur_y, cur_disp, pa, pb, pc);
+      const LevelArgs A = make_level<FUSED>(cd, s, v, cur_x, cur_y, pa, pb, pc);
+      double acc = 0.0;
+      for (int t = blk * 64 + lane; t < cd.groups * 64; t += 256) acc += tap_term<FUSED>(cd, A, lut, t);
+      s_part[cand][s][blk][lane] = acc;
+      cur_y /= 2; cur_x /= 2; cur_disp /= 2.0;
+    }
+  }
+  __syncthreads();
+  if (blk == 0 && have) {
+    double cost = 0.0;
+    for (int s = 0; s < levels; ++s) {
+      const double sc = wave_sum((s_part[cand][s][0][lane] + s_part[cand][s][1][lane]) +
+                                 (s_part[cand][s][2][lane] + s_part[cand][s][3][lane]));
+      if (CS) cost += sc * cd.lv[s].wgt;  // :182
+      else cost = sc;
+    }
+    if (lane == 0) s_cost[cand] = cost;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double best_cost = f.cost[i];
+    int pick = -1;
+    if (xs > 0 && s_cost[0] < best_cost) { best_cost = s_cost[0]; pick = 0; }
+    if (ys > 0 && s_cost[1] < best_cost) { best_cost = s_cost[1]; pick = 1; }
+    if (pick >= 0) {
+      const long long q = pick == 0 ? i - inc : i - (long long)inc * pm.W;
+      store_plane(f, i, f.nx[q], f.ny[q], f.nz[q], f.a[q], f.b[q], f.c[q], best_cost);
+    }
   }
 }
 
@@ -303,10 +405,10 @@ struct ViewCand {
   int *cx;      // target column
 };
 
-template <bool CS>
+template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc) {
-  __shared__ double s_lut[kLutSize];
-  load_lut(cd, s_lut);
+  __shared__ LutMem s_lut;
+  const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long i = wave_item(npix);
   if (i < 0) return;
@@ -324,7 +426,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v,
   if (cor_x >= 0 && cor_x < pm.W) {
     plane_param(nx, ny, nz, (double)cor_x, (double)y, disp, a, b, c);     // :263-265
     const double thr = dst.cost[(long long)y * pm.W + cor_x];
-    cost = eval_plane<CS>(cd, s_lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, pm.use_thresh != 0, lane);  // :266-267
+    cost = eval_plane<CS, FUSED>(cd, lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, pm.use_thresh != 0, lane);  // :266-267
   }
   if (lane == 0) {
     vc.cost[i] = cost;
@@ -367,14 +469,12 @@ __global__ __launch_bounds__(256) void k_view_resolve(Pm pm, int v, int reverse,
       const double nx = src.nx[row + x], ny = src.ny[row + x], nz = src.nz[row + x];
       double denom = fmax(fabs(nz), kDoubleEps);  // a, b of cor_plane.update_param() (plane.h:27-32)
       if (nz < 0.0) denom = -denom;
-      // NOTE: dst.cost[row+cx] is written below; every other thread reading it for the same cx lost
-      // the rank test above, and __syncthreads() separates the passes.
       dst.nx[row + cx] = nx; dst.ny[row + cx] = ny; dst.nz[row + cx] = nz;
       dst.a[row + cx] = -nx / denom; dst.b[row + cx] = -ny / denom; dst.c[row + cx] = vc.c[row + x];
     }
   }
   __syncthreads();
-  // costs last, so the `c < dst.cost` tests of the pass above saw the pre-pass values
+  // costs last, so the `c < dst.cost` tests of the passes above saw the pre-pass values
   for (int t = threadIdx.x; t < W; t += blockDim.x)
     if (s_rank[t] != 0xFFFFFFFFu) dst.cost[row + t] = key_f64(s_key[t]);
 }
@@ -406,19 +506,33 @@ __global__ void k_plane_to_disp_f64(Pm pm, int v, double *__restrict__ out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Image preparation: BGR8 -> packed u32, pyrDown (pre_cs_pc.cc:45), gray + x-gradient (grd_cc.cpp:70-77)
+// Image preparation: BGR8 -> packed u32 (padded), pyrDown (pre_cs_pc.cc:45), gray + x-gradient
+// (grd_cc.cpp:70-77).  All of it is < 0.1 % of the work: one thread per pixel, nothing clever.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pack_bgr(const uint8_t *__restrict__ src, size_t stride, int W, int H, uint32_t *__restrict__ dst) {
+// fills a whole padded level: interior from packed BGR rows, pad cells with the border constant
+__global__ void k_pack_bgr(const uint8_t *__restrict__ src, size_t stride, int W, int H, int Wp, int pad, uint32_t *__restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Wp * H) return;
+  const int y = (int)(i / Wp), xp = (int)(i - (long long)y * Wp), x = xp - pad;
+  uint32_t v = kBorderPix;
+  if (x >= 0 && x < W) {
+    const uint8_t *p = src + (size_t)y * stride + 3 * (size_t)x;
+    v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  }
+  dst[i] = v;
+}
+// unpadded W*H packed pixels -> padded level (pad cells = border constant)
+__global__ void k_pad_u32(const uint32_t *__restrict__ src, int W, int H, int Wp, int pad, uint32_t *__restrict__ dst) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Wp * H) return;
+  const int y = (int)(i / Wp), x = (int)(i - (long long)y * Wp) - pad;
+  dst[i] = (x >= 0 && x < W) ? src[(size_t)y * W + x] : kBorderPix;
+}
+__global__ void k_unpack_bgr(const uint32_t *__restrict__ src, int W, int H, int Wp, int pad, uint8_t *__restrict__ dst) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)W * H) return;
   const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  const uint8_t *p = src + (size_t)y * stride + 3 * (size_t)x;
-  dst[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-}
-__global__ void k_unpack_bgr(const uint32_t *__restrict__ src, int W, int H, uint8_t *__restrict__ dst) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)W * H) return;
-  const uint32_t p = src[i];
+  const uint32_t p = src[(size_t)y * Wp + pad + x];
   dst[3 * i] = (uint8_t)p; dst[3 * i + 1] = (uint8_t)(p >> 8); dst[3 * i + 2] = (uint8_t)(p >> 16);
 }
 
@@ -429,18 +543,20 @@ __device__ __forceinline__ int reflect101(int p, int len) {  // cv::borderInterp
 }
 
 // OpenCV 2.4 pyrDown on 8UC3: separable [1 4 6 4 1], integer accumulate, (v+128)>>8, REFLECT_101,
-// dst = ((W+1)/2, (H+1)/2).  One thread per destination pixel (25 taps; the pyramid is <0.1 % of the work).
-__global__ void k_pyrdown(const uint32_t *__restrict__ src, int W, int H, uint32_t *__restrict__ dst, int dW, int dH) {
+// dst = ((W+1)/2, (H+1)/2).  Writes the whole padded destination level.
+__global__ void k_pyrdown(const uint32_t *__restrict__ src, int W, int H, int sWp, int spad, uint32_t *__restrict__ dst, int dW,
+                          int dH, int dWp, int dpad) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)dW * dH) return;
-  const int y = (int)(i / dW), x = (int)(i - (long long)y * dW);
+  if (i >= (long long)dWp * dH) return;
+  const int y = (int)(i / dWp), xp = (int)(i - (long long)y * dWp), x = xp - dpad;
+  if (x < 0 || x >= dW) { dst[i] = kBorderPix; return; }
   const int kw[5] = {1, 4, 6, 4, 1};
   int acc[3] = {0, 0, 0};
   for (int ky = 0; ky < 5; ++ky) {
     const int sy = reflect101(2 * y + ky - 2, H);
     int row[3] = {0, 0, 0};
     for (int kx = 0; kx < 5; ++kx) {
-      const uint32_t p = src[(size_t)sy * W + reflect101(2 * x + kx - 2, W)];
+      const uint32_t p = src[(size_t)sy * sWp + spad + reflect101(2 * x + kx - 2, W)];
       row[0] += kw[kx] * (int)(p & 255u);
       row[1] += kw[kx] * (int)((p >> 8) & 255u);
       row[2] += kw[kx] * (int)((p >> 16) & 255u);
@@ -450,63 +566,72 @@ __global__ void k_pyrdown(const uint32_t *__restrict__ src, int W, int H, uint32
   dst[i] = (uint32_t)((acc[0] + 128) >> 8) | ((uint32_t)((acc[1] + 128) >> 8) << 8) | ((uint32_t)((acc[2] + 128) >> 8) << 16);
 }
 
-// pixel sources for the GRD kernels: packed u8 image of the ctx, or a CV_64FC3 RGB host volume
+// pixel sources for the GRD kernels: padded packed u8 image of the ctx, or a CV_64FC3 RGB host volume
 struct SrcU32 {
   const uint32_t *p;
-  __device__ __forceinline__ void rgb(size_t i, double &r, double &g, double &b) const {
-    const uint32_t q = p[i];
+  int Wp, pad;
+  __device__ __forceinline__ void rgb(int x, int y, double &r, double &g, double &b) const {
+    const uint32_t q = p[(size_t)y * Wp + pad + x];
     b = (double)(q & 255u); g = (double)((q >> 8) & 255u); r = (double)((q >> 16) & 255u);
   }
 };
 struct SrcF64 {
   const double *p;
-  __device__ __forceinline__ void rgb(size_t i, double &r, double &g, double &b) const { r = p[3 * i]; g = p[3 * i + 1]; b = p[3 * i + 2]; }
+  int W;
+  __device__ __forceinline__ void rgb(int x, int y, double &r, double &g, double &b) const {
+    const size_t i = (size_t)y * W + x;
+    r = p[3 * i]; g = p[3 * i + 1]; b = p[3 * i + 2];
+  }
 };
 
 // grd_cc.cpp:70-73: convertTo(CV_32F); cvtColor(CV_RGB2GRAY): gray = R*0.299f + G*0.587f + B*0.114f in float
 template <class Src>
-__device__ __forceinline__ float gray_at(const Src &s, size_t i) {
+__device__ __forceinline__ float gray_at(const Src &s, int x, int y) {
   double r, g, b;
-  s.rgb(i, r, g, b);
+  s.rgb(x, y, r, g, b);
   float t = (float)r * 0.299f;
   t = t + (float)g * 0.587f;
   t = t + (float)b * 0.114f;
   return t;
 }
-// grd_cc.cpp:76-77: Sobel(gray, CV_64F, 1, 0, ksize=1) = gray[x+1]-gray[x-1] in double, REFLECT_101
+// grd_cc.cpp:76-77: Sobel(gray, CV_64F, 1, 0, ksize=1) = gray[x+1]-gray[x-1] in double, REFLECT_101.
+// Output is a padded level (pad cells = BORDER_THRES) when gWp > W, else packed.
 template <class Src>
-__global__ void k_gradient(Src s, int W, int H, double *__restrict__ grd) {
+__global__ void k_gradient(Src s, int W, int H, int gWp, int gpad, double *__restrict__ grd) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)W * H) return;
-  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  const size_t row = (size_t)y * W;
-  grd[i] = (double)gray_at(s, row + reflect101(x + 1, W)) - (double)gray_at(s, row + reflect101(x - 1, W));
+  if (i >= (long long)gWp * H) return;
+  const int y = (int)(i / gWp), xp = (int)(i - (long long)y * gWp), x = xp - gpad;
+  double g = 3.0;  // BORDER_THRES (grd_cc.h:6)
+  if (x >= 0 && x < W) g = (double)gray_at(s, reflect101(x + 1, W), y) - (double)gray_at(s, reflect101(x - 1, W), y);
+  grd[i] = g;
 }
 
 // GrdCC::buildCV / buildRightCV (cc/grd_cc.cpp:60-154) with myCostGrd (:4-35); one thread per cell,
-// slabs d-major as Mat costVol[d].  Also reduces max over the volume (pre_cs_pc.cc:75-82).
+// slabs d-major as Mat costVol[d] (vol == nullptr: only the max is wanted).  Also reduces the max over
+// the volume (pre_cs_pc.cc:75-82).  d0/nd select a slab range (cspm_get_cost_slab in fused mode).
 //   left  view: other = right image at x-d, border branch when x-d < 0     (:88-100)
 //   right view: other = left image at x+d, border branch when x+d >= wid   (:134-147)
 template <class Src>
 __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *__restrict__ lG, const double *__restrict__ rG,
-                                                    int W, int H, int maxDis, int right_view, double *__restrict__ vol,
-                                                    unsigned long long *max_key) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long cells = (long long)W * H * maxDis;
-  double cost = -1.7976931348623157e308;
-  if (i < cells) {
-    const long long slab = (long long)W * H;
-    const int d = (int)(i / slab);
-    const long long o = i - (long long)d * slab;
+                                                    int gWp, int gpad, int W, int H, int d0, int nd, int right_view,
+                                                    double *__restrict__ vol, unsigned long long *max_key) {
+  const long long slab = (long long)W * H;
+  const long long cells = slab * nd;
+  double best = -1.7976931348623157e308;
+  // grid-stride: a bounded grid keeps the number of max-atomics (one per wave) small
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
+    double cost;
+    const int d = d0 + (int)(i / slab);
+    const long long o = i - (long long)(d - d0) * slab;
     const int y = (int)(o / W), x = (int)(o - (long long)y * W);
     const int xo = right_view ? x + d : x - d;
     const bool inside = right_view ? (xo < W) : (xo >= 0);
     double c0, c1, c2, g0;  // own pixel
     double o0, o1, o2, og;  // other-view pixel, or BORDER_THRES
-    if (right_view) { r.rgb((size_t)o, c0, c1, c2); g0 = rG[o]; } else { l.rgb((size_t)o, c0, c1, c2); g0 = lG[o]; }
+    const size_t grow = (size_t)y * gWp + gpad;
+    if (right_view) { r.rgb(x, y, c0, c1, c2); g0 = rG[grow + x]; } else { l.rgb(x, y, c0, c1, c2); g0 = lG[grow + x]; }
     if (inside) {
-      const size_t j = (size_t)y * W + xo;
-      if (right_view) { l.rgb(j, o0, o1, o2); og = lG[j]; } else { r.rgb(j, o0, o1, o2); og = rG[j]; }
+      if (right_view) { l.rgb(xo, y, o0, o1, o2); og = lG[grow + xo]; } else { r.rgb(xo, y, o0, o1, o2); og = rG[grow + xo]; }
     } else {
       o0 = o1 = o2 = 3.0; og = 3.0;  // BORDER_THRES (grd_cc.h:6)
     }
@@ -520,16 +645,17 @@ __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *
     clrDiff = clrDiff > 10.0 ? 10.0 : clrDiff;  // TAU_CLR
     grdDiff = grdDiff > 2.0 ? 2.0 : grdDiff;    // TAU_GRD
     cost = 0.1 * clrDiff + (1 - 0.1) * grdDiff; // ALPHA
-    vol[i] = cost;
+    if (vol) vol[i] = cost;
+    best = cost > best ? cost : best;
   }
-  // block max -> one atomic per wave
-  unsigned long long key = f64_key(cost);
+  // wave max -> one atomic per wave
+  unsigned long long key = f64_key(best);
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
     const unsigned long long other = __shfl_xor(key, off, kWave);
     key = other > key ? other : key;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(max_key, key);
+  if (max_key && (threadIdx.x & 63) == 0) atomicMax(max_key, key);
 }
 
 // max over an uploaded (foreign CCMethod) volume

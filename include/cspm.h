@@ -71,6 +71,13 @@ int cspm_set_images_device(cspm_ctx *ctx, const void *d_l_bgr, const void *d_r_b
  * scale_num >= 1 (pre_cs_pc.cc:12-115): pyramid, per-level GRD cost volumes of both views
  * (cc/grd_cc.cpp:60-154), max_cost, scale weights, exp LUT -- all on the device. */
 int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
+/* options (set before cspm_build_cost_grd).
+ * CSPM_OPT_GRD_VOLUMES: 0 (default) = GRD cell costs are recomputed on the fly from the images and
+ * gradients inside the PatchMatch kernels (bit-identical to reading GrdCC's volumes, no 1-30 GB cost
+ * volume in HBM); 1 = materialise the d-major f64 volumes exactly as PreCSPC does (pre_cs_pc.cc:50-73)
+ * and read them. */
+#define CSPM_OPT_GRD_VOLUMES 1
+int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
  * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */
 int cspm_begin_cost(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
@@ -91,7 +98,7 @@ int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
 
 /* ---- IPlaneCost::GetPlaneCost, batched (plane_cost/i_plane_cost.h:28-33) ----------------------
  * xy: 2 ints per item; plane: 6 doubles per item = Plane::norm() then Plane::param().
- * Summation order is the device order (DESIGN.md "LANE64"); differs from the reference's serial
+ * Summation order is the device order (DESIGN.md "SLOT256"); differs from the reference's serial
  * sum only by rounding. */
 int cspm_plane_cost_batch(cspm_ctx *ctx, int view, int n, const int *xy, const double *norm_param, double *cost_out);
 

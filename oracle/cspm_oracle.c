@@ -396,11 +396,26 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
   return wgt * tmp;
 }
 
-#define LANE64_CHECK_EVERY 4 /* LANE64 early-exit checkpoints: after every 4th 64-tap group and at level end */
+#define DEVICE_CHECK_EVERY 4 /* DEVICE early-exit checkpoints: after every 4th 64-tap group and at level end */
 
 /* aggregated cost of ONE level (inner loops of pre_cs_pc.cc:151-181 / pre_ss_pc.cc:82-115).
  * base/mul: total so far and the level's scale weight, used only for the early-exit test
- * base + partial*mul >= thresh.  Returns the level sum, or -1.0 if rejected early. */
+ * base + partial*mul >= thresh.  Returns the level sum, or -1.0 if rejected early.
+ *
+ * CSOR_SUM_DEVICE ("SLOT256"): tap t=(dy+half)*n+(dx+half) is accumulated, in t order,
+ * into slot t%256; the 256 slots are reduced as r[l] = (p[l]+p[l+64]) + (p[l+128]+p[l+192]),
+ * l<64, followed by an xor butterfly over r with offsets 1,2,4,8,16,32.  This is what one wavefront
+ * (4 accumulators per lane) or four cooperating wavefronts compute. */
+static double slot_reduce(const double *p) {
+  double v[64], u[64];
+  for (int l = 0; l < 64; ++l) v[l] = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
+  for (int off = 1; off < 64; off <<= 1) {
+    for (int l = 0; l < 64; ++l) u[l] = v[l] + v[l ^ off];
+    memcpy(v, u, sizeof v);
+  }
+  return v[0];
+}
+
 static double level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double a, double b, double c,
                          int sum_order, double base, double mul, double thresh, int use_thresh, long long *taps) {
   const int half = pc->half_wnd, W = pc->wid[s], H = pc->hei[s];
@@ -422,10 +437,9 @@ static double level_cost(const csor_pc *pc, int view, int s, int cx, int cy, dou
     if (taps) *taps += nt;
     return acc;
   }
-  /* LANE64: tap t=(dy+half)*n+(dx+half) belongs to lane t%64, group t/64 */
   const int n = 2 * half + 1, T = n * n, groups = (T + 63) / 64;
-  double part[64];
-  for (int l = 0; l < 64; ++l) part[l] = 0.0;
+  double part[256];
+  for (int l = 0; l < 256; ++l) part[l] = 0.0;
   for (int g = 0; g < groups; ++g) {
     for (int l = 0; l < 64; ++l) {
       const int t = g * 64 + l;
@@ -433,20 +447,15 @@ static double level_cost(const csor_pc *pc, int view, int s, int cx, int cy, dou
       const int q_y = cy + t / n - half, q_x = cx + t % n - half;
       if (q_y >= 0 && q_y < H && q_x >= 0 && q_x < W) {
         const double q_disp_y = b * q_y + c;
-        part[l] += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y);
+        part[t % 256] += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y);
         ++nt;
       }
     }
     const int last = (g == groups - 1);
-    if (last || (use_thresh && (g % LANE64_CHECK_EVERY) == LANE64_CHECK_EVERY - 1)) {
-      double v[64], u[64];
-      memcpy(v, part, sizeof v);
-      for (int off = 1; off < 64; off <<= 1) { /* xor butterfly, ascending */
-        for (int l = 0; l < 64; ++l) u[l] = v[l] + v[l ^ off];
-        memcpy(v, u, sizeof v);
-      }
-      if (use_thresh && base + v[0] * mul >= thresh) { if (taps) *taps += nt; return -1.0; }
-      if (last) { if (taps) *taps += nt; return v[0]; }
+    if (last || (use_thresh && (g % DEVICE_CHECK_EVERY) == DEVICE_CHECK_EVERY - 1)) {
+      const double tot = slot_reduce(part);
+      if (use_thresh && base + tot * mul >= thresh) { if (taps) *taps += nt; return -1.0; }
+      if (last) { if (taps) *taps += nt; return tot; }
     }
   }
   if (taps) *taps += nt;

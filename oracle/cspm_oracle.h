@@ -31,7 +31,8 @@ enum { CSOR_LEFT = 0, CSOR_RIGHT = 1 };           /* commfunc.h:29  enum RefView
 /* summation order inside GetPlaneCost */
 enum {
   CSOR_SUM_SERIAL = 0,  /* reference order: dy outer, dx inner, one accumulator (pre_cs_pc.cc:151-181) */
-  CSOR_SUM_LANE64 = 1   /* device order: tap t -> lane t%64, per-lane accumulators, xor-butterfly 1,2,..,32 */
+  CSOR_SUM_DEVICE = 1   /* device order "SLOT256": tap t -> slot t%256, per-slot accumulators in t order,
+                           r[l]=(p[l]+p[l+64])+(p[l+128]+p[l+192]), then xor-butterfly 1,2,..,32 over r */
 };
 
 /* propagation schedule of SpatialPropagation */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libcspm_oracle.so")
 
 LEFT, RIGHT = 0, 1
-SUM_SERIAL, SUM_LANE64 = 0, 1
+SUM_SERIAL, SUM_DEVICE = 0, 1
 SCHED_RASTER, SCHED_REDBLACK = 0, 1
 RNG_PER_PIXEL, RNG_ROW_SHARED = 0, 1
 

@@ -12,17 +12,18 @@ pytestmark = pytest.mark.gpu
 CASES = [("ss", 0, 0.0), ("cs0", 5, 0.0), ("cs03", 5, 0.3), ("cs1", 5, 1.0), ("cs3lv", 3, 0.3)]
 
 
-def _build(ctx, pair, scale_num, lam, wnd=35):
+def _build(ctx, pair, scale_num, lam, wnd=35, volumes=False):
     ctx.set_images(pair["l"], pair["r"])
-    ctx.build_cost_grd(pair["max_dis"], wnd, scale_num, lam)
+    ctx.build_cost_grd(pair["max_dis"], wnd, scale_num, lam, volumes=volumes)
     return po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], wnd, scale_num, lam)
 
 
+@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
 @pytest.mark.parametrize("name,scale_num,lam", CASES)
-def test_pyramid_volumes_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam):
+def test_pyramid_volumes_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam, volumes):
     pair = request.getfixturevalue(pairname)
-    pc = _build(gpu_ctx, pair, scale_num, lam)
+    pc = _build(gpu_ctx, pair, scale_num, lam, volumes=volumes)
     assert gpu_ctx.levels == pc.levels
     np.testing.assert_array_equal(gpu_ctx.scale_weights(), pc.scale_wgt())
     for s in range(pc.levels):
@@ -55,18 +56,19 @@ def test_grd_build_cv_host_boundary(small_pair):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
 @pytest.mark.parametrize("name,scale_num,lam", CASES)
-def test_plane_cost_batch(gpu_ctx, request, pairname, name, scale_num, lam):
+def test_plane_cost_batch(gpu_ctx, request, pairname, name, scale_num, lam, volumes):
     """T2: >= 10^4 random (x, y, plane, view) tuples incl. corners, |nz|~0, out-of-range disparities."""
     pair = request.getfixturevalue(pairname)
-    pc = _build(gpu_ctx, pair, scale_num, lam)
+    pc = _build(gpu_ctx, pair, scale_num, lam, volumes=volumes)
     rng = np.random.default_rng(99)
     n = 5200
     for view in (0, 1):
         xy, norm, point, param = random_planes(rng, n, pair["w"], pair["h"], pair["max_dis"])
         got = gpu_ctx.plane_cost_batch(view, xy, np.concatenate([norm, param], 1))
-        lane = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], view, po.SUM_LANE64) for i in range(n)])
+        lane = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], view, po.SUM_DEVICE) for i in range(n)])
         np.testing.assert_array_equal(got, lane)  # same summation order: bit-exact
         idx = rng.choice(n, 600, replace=False)
         idx[:14] = np.arange(14)
@@ -81,7 +83,7 @@ def test_small_window(gpu_ctx, small_pair):
         rng = np.random.default_rng(wnd)
         xy, norm, point, param = random_planes(rng, 64, small_pair["w"], small_pair["h"], small_pair["max_dis"])
         got = gpu_ctx.plane_cost_batch(0, xy, np.concatenate([norm, param], 1))
-        want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 0, po.SUM_LANE64) for i in range(64)])
+        want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 0, po.SUM_DEVICE) for i in range(64)])
         np.testing.assert_array_equal(got, want)
 
 
@@ -107,7 +109,7 @@ def test_foreign_cost_volume_upload(gpu_ctx, small_pair):
             assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
     xy, norm, point, param = random_planes(rng, 256, small_pair["w"], small_pair["h"], small_pair["max_dis"])
     got = gpu_ctx.plane_cost_batch(1, xy, np.concatenate([norm, param], 1))
-    want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 1, po.SUM_LANE64) for i in range(256)])
+    want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 1, po.SUM_DEVICE) for i in range(256)])
     np.testing.assert_array_equal(got, want)
 
 

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 MODES = [("ss", 0, 0.0), ("cs", 5, 0.3)]
 
 
-def _setup(ctx, pair, scale_num, lam):
+def _setup(ctx, pair, scale_num, lam, volumes=False):
     ctx.set_images(pair["l"], pair["r"])
-    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam)
+    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam, volumes=volumes)
     pc = po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], 35, scale_num, lam)
     pm = po.PatchMatch(pair["l"], pair["r"], pair["max_dis"], 4)
     return pc, pm
@@ -28,11 +28,12 @@ def _assert_state_equal(ctx, pm, what):
         np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"{what}: min_cost, view {v}")
 
 
+@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("name,scale_num,lam", MODES)
 @pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
-def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched):
-    pc, pm = _setup(gpu_ctx, small_pair, scale_num, lam)
-    kw_o = dict(seed=777, schedule=sched, sum_order=po.SUM_LANE64, rb_rounds=2, rb_neighbours=4)
+def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched, volumes):
+    pc, pm = _setup(gpu_ctx, small_pair, scale_num, lam, volumes)
+    kw_o = dict(seed=777, schedule=sched, sum_order=po.SUM_DEVICE, rb_rounds=2, rb_neighbours=4)
     kw_g = dict(seed=777, schedule=sched, rb_rounds=2, rb_neighbours=4, early_exit=1)
     pm.init(pc, **kw_o); gpu_ctx.pm_init(**kw_g)
     _assert_state_equal(gpu_ctx, pm, "init")
@@ -52,7 +53,7 @@ def test_whole_pipeline_bit_exact(gpu_ctx, request, pairname, name, scale_num, l
     """T3/T4: PatchMatch(3, plane_cost, false) + PlaneToDisp."""
     pair = request.getfixturevalue(pairname)
     pc, pm = _setup(gpu_ctx, pair, scale_num, lam)
-    pm.run(3, pc, False, seed=4242, schedule=sched, sum_order=po.SUM_LANE64, rb_rounds=1, rb_neighbours=4)
+    pm.run(3, pc, False, seed=4242, schedule=sched, sum_order=po.SUM_DEVICE, rb_rounds=1, rb_neighbours=4)
     gpu_ctx.patchmatch(3, seed=4242, schedule=sched, rb_rounds=1, rb_neighbours=4, early_exit=1)
     _assert_state_equal(gpu_ctx, pm, "final")
     for v in (0, 1):
@@ -86,7 +87,7 @@ def test_early_exit_is_result_preserving(gpu_ctx, small_pair):
 def test_row_shared_rng_quirk(gpu_ctx, small_pair):
     """USE_OMP quirk (cs_patchmatch.cc:129-131): every row draws the same stream."""
     pc, pm = _setup(gpu_ctx, small_pair, 0, 0.0)
-    pm.init(pc, seed=9, rng_mode=po.RNG_ROW_SHARED, sum_order=po.SUM_LANE64)
+    pm.init(pc, seed=9, rng_mode=po.RNG_ROW_SHARED, sum_order=po.SUM_DEVICE)
     gpu_ctx.pm_init(seed=9, rng_mode=1)
     _assert_state_equal(gpu_ctx, pm, "init row-shared")
     npar, _ = gpu_ctx.get_planes(0)
@@ -108,5 +109,5 @@ def test_set_planes_roundtrip_and_view_ties(gpu_ctx, small_pair):
             P[..., 6:8] = 0.0; P[..., 8] = d
             pm.min_cost(v)[...] = 1e9
             gpu_ctx.set_planes(v, np.concatenate([P[..., 0:3], P[..., 6:9]], -1), pm.min_cost(v))
-        pm.view(it, pc, sum_order=po.SUM_LANE64); gpu_ctx.pm_view(it)
+        pm.view(it, pc, sum_order=po.SUM_DEVICE); gpu_ctx.pm_view(it)
         _assert_state_equal(gpu_ctx, pm, f"view ties iter {it}")
