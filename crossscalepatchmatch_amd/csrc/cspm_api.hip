@@ -237,6 +237,9 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     for (int v = 0; v < 2; ++v) {
       uint32_t *img;
       if ((rc = dalloc(c, &img, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
+      PixG *px;
+      if ((rc = dalloc(c, &px, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
+      L.px[v] = px;
       L.pix[v] = img;
       L.grd[v] = nullptr;
       L.vol[v] = nullptr;
@@ -552,6 +555,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
       Timed t(c, CSPM_K_GRD, 0);
       hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H,
                          L.Wp, L.pad, g);
+      hipLaunchKernelGGL(k_make_aos, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)g, ppx, (PixG *)L.px[v]);
     }
     const long long cells = (long long)L.W * L.H * (L.D + 1);
     for (int v = 0; v < 2; ++v) {
@@ -576,6 +580,8 @@ int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, doubl
     for (int v = 0; v < 2; ++v) {
       const Level &L = c->cost.lv[s];
       HIPCHK(c, hipMemsetAsync((void *)L.vol[v], 0, sizeof(double) * (size_t)(L.D + 1) * L.W * L.H, c->stream));  // Mat::zeros, pre_cs_pc.cc:52
+      hipLaunchKernelGGL(k_make_aos, dim3(ew_grid((long long)L.Wp * L.H)), dim3(256), 0, c->stream, L.pix[v], (const double *)nullptr,
+                         (long long)L.Wp * L.H, (PixG *)L.px[v]);
     }
   return CSPM_OK;
 }

@@ -14,6 +14,8 @@ namespace cspm {
 constexpr double kDoubleEps = 0.00000001;  // commfunc.h:26
 constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_limits<double>::max()
 constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
+constexpr int kLutZero = 767;              // entry forced to 0.0: masked taps read it, so they add wgt*tmp = +0.0
+constexpr int kTabSize = 128;              // per-wave tables a*qx / b*qy+c, one entry per window column / row
 constexpr int kWave = 64;
 constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup
 constexpr int kDiagBlock = 512;            // raster-sweep kernel: 8 waves cooperate on one pixel (2 candidates x 4 slot blocks)
@@ -23,12 +25,23 @@ constexpr uint32_t kBorderPix = 0x00030303u;  // BORDER_THRES in B, G and R (cc/
 // Images are stored PADDED: row stride Wp = W + 2*pad, image column x at index pad + x, pad = D + 2.
 // Pad cells hold the GRD border constant (BORDER_THRES = 3 for every channel and for the gradient,
 // cc/grd_cc.h:6), so the fused cost needs no border branch (cc/grd_cc.cpp:88-100, 134-147).
+// The PatchMatch kernels read the array-of-structs `px`: one 16-byte element per pixel = packed colour
+// + x-gradient, so one dwordx4 load fetches everything a tap needs of a pixel (the L1 address path
+// charges a wave64 load ~16 cycles whatever its width).
+struct PixG {
+  uint32_t pix;  // B | G<<8 | R<<16 (byte 3 = 0)
+  uint32_t spare;
+  double g;      // x-gradient of the f32 gray image (grd_cc.cpp:70-77); GRD only
+};
+static_assert(sizeof(PixG) == 16, "PixG must be 16 bytes");
+
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
   int Wp, pad;
-  const uint32_t *pix[2]; // packed B | G<<8 | R<<16 (byte 3 = 0), H rows of Wp
-  const double *grd[2];   // x-gradient of the f32 gray image (grd_cc.cpp:70-77), H rows of Wp; GRD only
-  const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; may be null when fused
+  const PixG *px[2];      // H rows of Wp
+  const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
+  const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only
+  const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; null when fused
   double wgt;             // scale_wgt_[s]
 };
 

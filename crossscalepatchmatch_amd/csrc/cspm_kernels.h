@@ -30,96 +30,150 @@ namespace cspm {
 // IPlaneCost::GetPlaneCost  (PreSSPC: pre_ss_pc.cc:74-118, PreCSPC: pre_cs_pc.cc:133-188)
 // ------------------------------------------------------------------------------------------------
 struct Luts {
-  const double *w;  // exp(-i/10)                        (pre_cs_pc.cc:111-114)
-  const double *a;  // ALPHA*min(i*0.3333333333,TAU_CLR)  (grd_cc.cpp:8-18), fused path only
+  const double *w;  // exp(-i/10), entry kLutZero = 0                 (pre_cs_pc.cc:111-114)
+  const double *a;  // ALPHA*min(i*0.3333333333,TAU_CLR)               (grd_cc.cpp:8-18), fused path only
+  double *tab;      // this wave's tables: tab[dx] = a*qx, tab[kTabSize+dy] = b*qy+c
 };
 
 // everything one level needs, wave-uniform
 struct LevelArgs {
-  int W, H, Wp, pad, cx, cy, dir;
-  double Dd, maxc, a, b, c;
-  const uint32_t *pix, *opix;
-  const double *grd, *ogrd, *vol;
+  int W, H, Wp, ox0, oy0, obase, ocen, dir;
+  double Dd, maxc;
+  const PixG *px, *opx;
+  const double *vol;
   size_t slab;
   uint32_t Ip;
 };
 
-template <bool FUSED>
-__device__ __forceinline__ LevelArgs make_level(const Cost &cd, int s, int view, int cx, int cy, double a, double b, double c) {
+// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS queue of a wave is
+// in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint4 ld16(const PixG *base, unsigned idx) {  // 32-bit offset: saddr + voffset addressing
+  uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 4));
+  asm volatile("" ::"v"(v.y));  // demand the spare dword: keeps ONE global_load_dwordx4 instead of dword + dwordx2
+  return v;
+}
+__device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double((int)v.w, (int)v.z); }
+
+// Prepare one level for this wave: uniform arguments plus the two per-wave tables
+//   tab[dx]          = plane_a * q_x            (the product of pre_cs_pc.cc:165)
+//   tab[kTabSize+dy] = plane_b * q_y + plane_c  (q_disp_y, pre_cs_pc.cc:155)
+// so that a tap's q_disp is one add of two LDS reads instead of two int->f64 converts, two multiplies
+// and two adds -- bit-identical, each table entry is rounded exactly like the expression it replaces.
+__device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut, int s, int view, int cx, int cy, double a,
+                                                double b, double c, int lane) {
   const Level &L = cd.lv[s];
   LevelArgs A;
-  A.W = L.W; A.H = L.H; A.Wp = L.Wp; A.pad = L.pad; A.cx = cx; A.cy = cy;
+  A.W = L.W; A.H = L.H; A.Wp = L.Wp;
+  A.ox0 = cx - cd.half; A.oy0 = cy - cd.half;
+  A.obase = A.oy0 * L.Wp + L.pad + A.ox0;  // element index of window tap (0,0); may be negative, used masked
+  A.ocen = cy * L.Wp + L.pad + cx;
   A.dir = view == 0 ? -1 : 1;  // left view looks at x-d in the right image, right view at x+d in the left
   A.Dd = (double)L.D;
   A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
-  A.a = a; A.b = b; A.c = c;
-  A.pix = L.pix[view]; A.opix = L.pix[1 - view];
-  A.grd = L.grd[view]; A.ogrd = L.grd[1 - view];
+  A.px = L.px[view]; A.opx = L.px[1 - view];
   A.vol = L.vol[view];
   A.slab = (size_t)L.W * (size_t)L.H;
-  A.Ip = A.pix[(size_t)cy * L.Wp + L.pad + cx];
+  A.Ip = L.px[view][A.ocen].pix;
+  wave_lds_fence();  // the previous level's table reads are done
+  for (int l = lane; l < cd.n; l += kWave) {
+    lut.tab[l] = a * (double)(A.ox0 + l);
+    lut.tab[kTabSize + l] = b * (double)(A.oy0 + l) + c;
+  }
+  wave_lds_fence();
   return A;
 }
 
 // myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
 // arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
-// TAU_CLR) is a table of the SAD.
-__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, uint32_t Io, double Go) {
-  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, Io, 0u);
-  double grdDiff = fabs(Gq - Go);
-  grdDiff = grdDiff > 2.0 ? 2.0 : grdDiff;  // TAU_GRD
-  return lut.a[sad] + (1 - 0.1) * grdDiff;  // ALPHA*clrDiff + (1-ALPHA)*grdDiff
+// TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
+__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const uint4 &o) {
+  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, o.x, 0u);
+  const double grdDiff = __builtin_fmin(fabs(Gq - g_of(o)), 2.0);  // TAU_GRD
+  return lut.a[sad] + (1 - 0.1) * grdDiff;                         // ALPHA*clrDiff + (1-ALPHA)*grdDiff
 }
 
-// One window tap t (pre_cs_pc.cc:157-179): returns wgt * interpolated cell cost, or +0.0 for taps
-// outside the window / image.  Branch-free: masked lanes read the centre pixel.
+// v_cvt_i32_f64 saturates and maps NaN to 0; written as asm because (int)double is undefined out of range.
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// One window tap t (pre_cs_pc.cc:157-179): returns wgt * interpolated cell cost; taps outside the
+// window / image read the centre pixel with weight entry kLutZero (= 0.0) and so add +0.0.
+// NB: every `c ? x : y` has plain locals on both sides.  clang emits a real branch for a conditional
+// operator with a member access in an arm, and LLVM then sinks all loads of the tap into that branch,
+// which serialises the four taps of a round behind s_waitcnt vmcnt(0).
 template <bool FUSED>
 __device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
-  // NB: every `c ? x : y` below has plain locals on both sides.  clang emits a real branch for a
-  // conditional operator with a member access in an arm, and LLVM then sinks all loads of this tap
-  // into that branch, which serialises the four taps of a round behind s_waitcnt vmcnt(0).
-  const int ccx = A.cx, ccy = A.cy;
-  const double maxc = A.maxc, zero = 0.0, one = 1.0;
+  const int ocen = A.ocen, lutzero = kLutZero, one = 1;
+  const double maxc = A.maxc;
   const int dy = (int)(((float)t + 0.5f) * cd.inv_n);
-  const int dx = t - dy * cd.n;
-  const int qy0 = ccy + dy - cd.half, qx0 = ccx + dx - cd.half;
-  const bool ok = (t < cd.T) & ((unsigned)qy0 < (unsigned)A.H) & ((unsigned)qx0 < (unsigned)A.W);
-  const int qy = ok ? qy0 : ccy, qx = ok ? qx0 : ccx;
-  const size_t row = (size_t)qy * A.Wp + A.pad;
-  const uint32_t Iq = A.pix[row + qx];
-  const int sum = (int)__builtin_amdgcn_sad_u8(A.Ip, Iq, 0u);  // |dB|+|dG|+|dR|  (:161-163)
-  const double wgt = lut.w[sum];                               // :164
-  const double q_disp_y = A.b * (double)qy + A.c;              // :155
-  const double q_disp = A.a * (double)qx + q_disp_y;           // :165
+  const int dx = t - __mul24(dy, cd.n);  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
+  const bool ok = (t < cd.T) & ((unsigned)(A.oy0 + dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + dx) < (unsigned)A.W);
+  const int o0 = A.obase + __mul24(dy, A.Wp) + dx;
+  const int o = ok ? o0 : ocen;
+  const uint4 P = ld16(A.px, (unsigned)o);
+  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, P.x, 0u);  // |dB|+|dG|+|dR|  (:161-163)
+  const int sum = ok ? sum0 : lutzero;
+  const double wgt = lut.w[sum];                                 // :164
+  const double q_disp = lut.tab[dx] + lut.tab[kTabSize + dy];    // :155,165 (masked taps: any finite or NaN value)
   // static_cast<int>(q_disp) in [1, D-1]  <=>  1.0 <= q_disp < D; NaN / out of int range -> the
   // "impossible disparity" branch (:166-169), as x86 cvttsd2si (INT_MIN) takes it.
   const bool valid = (q_disp >= 1.0) & (q_disp < A.Dd);
-  const int f = (int)(valid ? q_disp : one);
-  const double floor_wgt = (double)(f + 1) - q_disp;           // :171-172
+  const int f0 = cvt_i32_sat(q_disp);
+  const int f = valid ? f0 : one;
+  const double floor_wgt = (double)(f + 1) - q_disp;             // :171-172
   double c0, c1;
   if (FUSED) {
-    const double Gq = A.grd[row + qx];
-    const size_t of = row + (qx + A.dir * f), oc = of + A.dir;
-    c0 = grd_cell(lut, Iq, Gq, A.opix[of], A.ogrd[of]);
-    c1 = grd_cell(lut, Iq, Gq, A.opix[oc], A.ogrd[oc]);
+    const double Gq = g_of(P);
+    const int of = o + __mul24(A.dir, f);
+    c0 = grd_cell(lut, P.x, Gq, ld16(A.opx, (unsigned)of));
+    c1 = grd_cell(lut, P.x, Gq, ld16(A.opx, (unsigned)(of + A.dir)));
   } else {
-    const double *p = A.vol + (size_t)f * A.slab + (size_t)qy * A.W + qx;
+    const int dyc = ok ? dy : cd.half, dxc = ok ? dx : cd.half;
+    const double *p = A.vol + (size_t)f * A.slab + (size_t)(A.oy0 + dyc) * A.W + (A.ox0 + dxc);
     c0 = p[0];
     c1 = p[A.slab];
   }
-  double tmp = floor_wgt * c0 + (1 - floor_wgt) * c1;          // :173-175
-  tmp = valid ? tmp : maxc;                                    // :169
-  const double term = wgt * tmp;                               // :176
-  return ok ? term : zero;
+  double tmp = floor_wgt * c0 + (1 - floor_wgt) * c1;            // :173-175
+  tmp = valid ? tmp : maxc;                                      // :169
+  return wgt * tmp;                                              // :176
+}
+
+// Cheap wave-wide LOWER-BOUND sum for the early-exit test: f32 DPP reduction (6 VALU instructions, no
+// LDS).  The per-lane f64 partial is rounded toward zero to f32 and the f32 sum is scaled by (1 - 2^-16)
+// (64 round-to-nearest additions inflate it by < 64*2^-24), so the returned value never exceeds the
+// exact SLOT256 sum of the same partials: a candidate rejected on it would have been rejected anyway.
+__device__ __forceinline__ float wave_lower_bound(double part) {
+  float v = __double2float_rz(part);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));  // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));  // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));  // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));  // row_shr:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+  const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return tot * 0.99998474f;  // 1 - 2^-16
 }
 
 // One level, one wave: returns the level sum (identical in all lanes) or -1.0 once
 // base + partial*mul >= thresh is proven (all terms are >= 0: monotone, so the candidate is rejected).
+// The proof uses the cheap lower bound after every round of 256 taps and the exact sum at the level end.
 template <bool FUSED>
 __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A, const Luts &lut, double base, double mul,
                                              double thresh, bool use_thresh, int lane) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   const int rounds = (cd.groups + 3) / 4;
+  // exit when base + S*mul >= thresh, S >= lb: implied by lb > (thresh-base)/mul * (1+1e-6); the margin
+  // covers the roundings of this expression and of the float conversion (mul == 0 gives inf/NaN: no exit)
+  const float need = use_thresh ? (float)(((thresh - base) / mul) * 1.000001) : 0.0f;
   for (int i = 0; i < rounds; ++i) {
     const int t = i * 256 + lane;
     const double t0 = tap_term<FUSED>(cd, A, lut, t);
@@ -127,14 +181,12 @@ __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A,
     const double t2 = tap_term<FUSED>(cd, A, lut, t + 128);
     const double t3 = tap_term<FUSED>(cd, A, lut, t + 192);
     a0 += t0; a1 += t1; a2 += t2; a3 += t3;
-    const bool last = (i == rounds - 1);
-    if (last || use_thresh) {
-      const double tot = wave_sum((a0 + a1) + (a2 + a3));
-      if (use_thresh && base + tot * mul >= thresh) return -1.0;
-      if (last) return tot;
-    }
+    if (i == rounds - 1) break;
+    if (use_thresh && wave_lower_bound((a0 + a1) + (a2 + a3)) > need) return -1.0;
   }
-  return 0.0;
+  const double tot = wave_sum((a0 + a1) + (a2 + a3));
+  if (use_thresh && base + tot * mul >= thresh) return -1.0;
+  return tot;
 }
 
 // Aggregated plane cost at (x,y); +inf when the candidate is proven not to beat `thresh`.
@@ -144,7 +196,7 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
                                              double nz, double pa, double pb, double pc, double thresh, bool use_thresh,
                                              int lane) {
   if (!CS) {
-    const LevelArgs A = make_level<FUSED>(cd, 0, view, x, y, pa, pb, pc);
+    const LevelArgs A = make_level(cd, lut, 0, view, x, y, pa, pb, pc, lane);
     const double r = level_cost<FUSED>(cd, A, lut, 0.0, 1.0, thresh, use_thresh, lane);
     return r < 0.0 ? __builtin_inf() : r;
   }
@@ -155,7 +207,7 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
     double a, b, c;
     plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
     const double wgt = cd.lv[s].wgt;
-    const LevelArgs A = make_level<FUSED>(cd, s, view, cur_x, cur_y, a, b, c);
+    const LevelArgs A = make_level(cd, lut, s, view, cur_x, cur_y, a, b, c, lane);
     const double sc = level_cost<FUSED>(cd, A, lut, cost, wgt, thresh, use_thresh, lane);
     if (sc < 0.0) return __builtin_inf();
     cost += sc * wgt;  // :182
@@ -166,17 +218,22 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
   return cost;
 }
 
+template <int WAVES>
 struct LutMem {
   double w[kLutSize];
   double a[kLutSize];
+  double tab[WAVES][2 * kTabSize];
 };
-__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem &m) {
+template <int WAVES>
+__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem<WAVES> &m) {
   for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) {
-    m.w[i] = cd.lut[i];
+    m.w[i] = i == kLutZero ? 0.0 : cd.lut[i];
     m.a[i] = cd.lut_a[i];
   }
+  for (int i = threadIdx.x; i < WAVES * 2 * kTabSize; i += blockDim.x) (&m.tab[0][0])[i] = 0.0;
   __syncthreads();
-  return Luts{m.w, m.a};
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  return Luts{m.w, m.a, m.tab[wave]};
 }
 
 // Work item (candidate) index of this wave.  Blocks are dealt round-robin to the 8 XCDs; give XCD k
@@ -204,7 +261,7 @@ __device__ __forceinline__ void store_plane(const Field &f, long long i, double 
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, int n, const int *__restrict__ xy,
                                                            const double *__restrict__ np, double *__restrict__ out) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
   const long long e = wave_item(n);
   if (e < 0) return;
@@ -220,7 +277,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, in
 // ------------------------------------------------------------------------------------------------
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long e = wave_item(2 * npix);
@@ -256,7 +313,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
 // ------------------------------------------------------------------------------------------------
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter, int step, double z_iter, double n_iter) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long e = wave_item(2 * npix);
@@ -292,7 +349,7 @@ struct Cand { double nx, ny, nz, a, b, c; };
 
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int colour, int inc, int nb) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
   const int halfW = (pm.W + 1) / 2;
   const long long per_view = (long long)halfW * pm.H;
@@ -333,7 +390,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // ------------------------------------------------------------------------------------------------
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kDiagBlock / kWave> s_lut;
   __shared__ double s_part[2][CSPM_MAX_LEVELS][4][kWave];
   __shared__ double s_cost[2];
   const Luts lut = load_luts(cd, s_lut);
@@ -359,9 +416,20 @@ __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int
     for (int s = 0; s < levels; ++s) {
       double pa = c.a, pb = c.b, pc = c.c;
       if (CS) plane_param(c.nx, c.ny, c.nz, (double)cur_x, (double)cur_y, cur_disp, pa, pb, pc);
-      const LevelArgs A = make_level<FUSED>(cd, s, v, cur_x, cur_y, pa, pb, pc);
+      const LevelArgs A = make_level(cd, lut, s, v, cur_x, cur_y, pa, pb, pc, lane);
       double acc = 0.0;
-      for (int t = blk * 64 + lane; t < cd.groups * 64; t += 256) acc += tap_term<FUSED>(cd, A, lut, t);
+      const int rounds = (cd.groups + 3) / 4;
+      int i = 0;
+      for (; i + 5 <= rounds; i += 5) {  // 5 independent taps per trip: their loads are issued together
+        const int t = i * 256 + blk * 64 + lane;
+        const double t0 = tap_term<FUSED>(cd, A, lut, t);
+        const double t1 = tap_term<FUSED>(cd, A, lut, t + 256);
+        const double t2 = tap_term<FUSED>(cd, A, lut, t + 512);
+        const double t3 = tap_term<FUSED>(cd, A, lut, t + 768);
+        const double t4 = tap_term<FUSED>(cd, A, lut, t + 1024);
+        acc += t0; acc += t1; acc += t2; acc += t3; acc += t4;
+      }
+      for (; i < rounds; ++i) acc += tap_term<FUSED>(cd, A, lut, i * 256 + blk * 64 + lane);
       s_part[cand][s][blk][lane] = acc;
       cur_y /= 2; cur_x /= 2; cur_disp /= 2.0;
     }
@@ -407,7 +475,7 @@ struct ViewCand {
 
 template <bool CS, bool FUSED>
 __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc) {
-  __shared__ LutMem s_lut;
+  __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
   const long long npix = (long long)pm.W * pm.H;
   const long long i = wave_item(npix);
@@ -520,6 +588,16 @@ __global__ void k_pack_bgr(const uint8_t *__restrict__ src, size_t stride, int W
     v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
   }
   dst[i] = v;
+}
+// interleave packed colour and gradient into the 16-byte elements the PatchMatch kernels read
+__global__ void k_make_aos(const uint32_t *__restrict__ pix, const double *__restrict__ grd, long long n, PixG *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PixG e;
+  e.pix = pix[i];
+  e.spare = 0u;
+  e.g = grd ? grd[i] : 0.0;
+  out[i] = e;
 }
 // unpadded W*H packed pixels -> padded level (pad cells = border constant)
 __global__ void k_pad_u32(const uint32_t *__restrict__ src, int W, int H, int Wp, int pad, uint32_t *__restrict__ dst) {
