@@ -50,6 +50,7 @@ struct cspm_ctx {
   Field f[2]{};
   ViewCand vc{nullptr, nullptr, nullptr};
   uint8_t *d_dis[2] = {nullptr, nullptr};
+  int *d_valid[2] = {nullptr, nullptr};
   // timing
   bool timing = false;
   std::vector<TimingRec> recs;
@@ -152,7 +153,9 @@ void free_field(cspm_ctx *c) {
   if (c->vc.cx) (void)hipFree(c->vc.cx);
   for (int v = 0; v < 2; ++v) {
     if (c->d_dis[v]) (void)hipFree(c->d_dis[v]);
+    if (c->d_valid[v]) (void)hipFree(c->d_valid[v]);
     c->d_dis[v] = nullptr;
+    c->d_valid[v] = nullptr;
   }
   c->field_mem = nullptr;
   c->vc = ViewCand{nullptr, nullptr, nullptr};
@@ -316,8 +319,10 @@ int ensure_field(cspm_ctx *c) {
   if ((rc = dalloc(c, &c->vc.cost, n, nullptr))) return rc;
   if ((rc = dalloc(c, &c->vc.c, n, nullptr))) return rc;
   if ((rc = dalloc(c, &c->vc.cx, n, nullptr))) return rc;
-  for (int v = 0; v < 2; ++v)
+  for (int v = 0; v < 2; ++v) {
     if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
+    if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
+  }
   c->field_alloc = true;
   return CSPM_OK;
 }
@@ -839,8 +844,30 @@ int cspm_get_disparity_f64(cspm_ctx *c, int view, double *out) {
 }
 
 int cspm_postprocess(cspm_ctx *c, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride) {
-  (void)dis_scale; (void)l_out; (void)r_out; (void)stride;
-  return fail(c, CSPM_ERR_STATE, "cspm_postprocess: not implemented yet (SURVEY.md 8(f) rank 1)");
+  if (!c) return CSPM_ERR_ARG;
+  if (!c->field_alloc || !c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_postprocess needs a finished PatchMatch");
+  if (dis_scale < 1 || stride < (size_t)c->W || !l_out || !r_out) return fail(c, CSPM_ERR_ARG, "bad dis_scale / stride / outputs");
+  HIPCHK(c, hipSetDevice(c->device));
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
+  const long long n = (long long)c->W * c->H;
+  const Level &L0 = c->cost.lv[0];
+  Timed t(c, CSPM_K_MISC, 0);
+  for (int v = 0; v < 2; ++v)  // PlaneToDisp (cs_patchmatch.cc:103)
+    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_dis[v], (size_t)c->W);
+  for (int v = 0; v < 2; ++v)  // LeftRightCheck (:516)
+    hipLaunchKernelGGL(k_lr_check, dim3(ew_grid(n)), dim3(256), 0, c->stream, c->d_dis[v], c->d_dis[1 - v], c->W, c->H, v, dis_scale, c->d_valid[v]);
+  for (int v = 0; v < 2; ++v)  // FillInvalid (:545)
+    hipLaunchKernelGGL(k_fill_invalid, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_valid[v], c->d_dis[v]);
+  for (int v = 0; v < 2; ++v)  // WeightedMedian(valid, 35, WMF_GAMMA) (:571-573); exp(-i/10) is the plane-cost LUT
+    hipLaunchKernelGGL(k_weighted_median, dim3(ew_grid(n, 64)), dim3(64), 0, c->stream, L0.pix[v], L0.Wp, L0.pad, c->W, c->H,
+                       c->d_valid[v], c->d_lut, c->d_dis[v], 35 / 2);
+  HIPCHK(c, hipGetLastError());
+  uint8_t *outs[2] = {l_out, r_out};
+  for (int v = 0; v < 2; ++v)
+    HIPCHK(c, hipMemcpy2DAsync(outs[v], stride, c->d_dis[v], c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return CSPM_OK;
 }
 
 int cspm_enable_timing(cspm_ctx *c, int on) {

@@ -574,6 +574,93 @@ __global__ void k_plane_to_disp_f64(Pm pm, int v, double *__restrict__ out) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// CSPatchMatch::PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps.  Deterministic integer /
+// f64 work, < 1 % of a run: one thread per pixel, loops exactly in the reference's order so that the
+// weighted-median histogram sums round identically.
+// ------------------------------------------------------------------------------------------------
+// LeftRightCheck (:347-369)
+__global__ void k_lr_check(const uint8_t *__restrict__ dis, const uint8_t *__restrict__ other, int W, int H, int v, int dis_scale,
+                           int *__restrict__ valid) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)W * H) return;
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  int ok = 0;
+  const double cur_dis = dis[i] * 1.0 / dis_scale;
+  const int other_x = x + (2 * v - 1) * round2int(cur_dis);
+  if (other_x >= 0 && other_x < W) {
+    const double other_dis = other[(size_t)y * W + other_x] * 1.0 / dis_scale;
+    if (fabs(cur_dis - other_dis) <= 0.5 && cur_dis > 0.0) ok = 1;
+  }
+  valid[i] = ok;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(int q) { return (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
+__device__ __forceinline__ double plane_disp_at(const Field &f, long long j, int x, int y) {
+  double d = f.a[j] * (double)x;  // param().dot(Vec3d(x, y, 1.0))
+  d += f.b[j] * (double)y;
+  d += f.c[j] * 1.0;
+  return d;
+}
+
+// FillInvalid (:370-428): nearest valid pixel to the left / right on the row, their planes evaluated at x
+__global__ void k_fill_invalid(Pm pm, int v, int dis_scale, const int *__restrict__ valid, uint8_t *__restrict__ dis) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)pm.W * pm.H) return;
+  if (valid[i]) return;
+  const int y = (int)(i / pm.W), x = (int)(i - (long long)y * pm.W);
+  const long long row = (long long)y * pm.W;
+  int l_first = x, r_first = x;
+  while (l_first >= 0 && !valid[row + l_first]) --l_first;
+  while (r_first < pm.W && !valid[row + r_first]) ++r_first;
+  const bool l_find = l_first >= 0, r_find = r_first < pm.W;
+  const Field &f = pm.f[v];
+  if (l_find && r_find) {
+    const double l_d = plane_disp_at(f, row + l_first, x, y), r_d = plane_disp_at(f, row + r_first, x, y);
+    dis[i] = sat_u8(dis_scale * round2int(l_d <= r_d ? l_d : r_d));
+  } else if (l_find) {
+    dis[i] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + l_first, x, y)));
+  } else if (r_find) {
+    dis[i] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + r_first, x, y)));
+  }
+}
+
+// WeightedMedian(valid, 35, WMF_GAMMA) (:430-506): invalid pixels only, valid neighbours only
+__global__ __launch_bounds__(64) void k_weighted_median(const uint32_t *__restrict__ pix, int Wp, int pad, int W, int H,
+                                                        const int *__restrict__ valid, const double *__restrict__ lut,
+                                                        uint8_t *__restrict__ dis, int half_wnd) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)W * H) return;
+  if (valid[i]) return;
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  double disp_hist[256];
+  for (int d = 0; d < 256; ++d) disp_hist[d] = 0.0;
+  const uint32_t p = pix[(size_t)y * Wp + pad + x];
+  double sum_wgt = 0.0;
+  for (int wy = -half_wnd; wy <= half_wnd; ++wy) {
+    const int qy = y + wy;
+    if (qy < 0 || qy >= H) continue;
+    for (int wx = -half_wnd; wx <= half_wnd; ++wx) {
+      const int qx = x + wx;
+      if (qx < 0 || qx >= W) continue;
+      const size_t q = (size_t)qy * W + qx;
+      if (!valid[q]) continue;
+      const int clr_diff = (int)__builtin_amdgcn_sad_u8(p, pix[(size_t)qy * Wp + pad + qx], 0u);
+      const double wgt = lut[clr_diff];
+      disp_hist[dis[q]] += wgt;
+      sum_wgt += wgt;
+    }
+  }
+  const double median_wgt = sum_wgt / 2.0;
+  sum_wgt = 0.0;
+  int median_disp = 0;
+  for (int d = 0; d < 256; ++d) {
+    sum_wgt += disp_hist[d];
+    if (sum_wgt >= median_wgt) { median_disp = d; break; }
+  }
+  if (median_wgt > 0.0) dis[i] = (uint8_t)median_disp;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Image preparation: BGR8 -> packed u32 (padded), pyrDown (pre_cs_pc.cc:45), gray + x-gradient
 // (grd_cc.cpp:70-77).  All of it is < 0.1 % of the work: one thread per pixel, nothing clever.
 // ------------------------------------------------------------------------------------------------

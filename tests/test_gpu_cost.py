@@ -125,3 +125,19 @@ def test_errors(gpu_ctx, small_pair):
     gpu_ctx.build_cost_grd(16, 35, 0, 0.0)
     with pytest.raises(cs.CspmError):
         gpu_ctx.plane_cost_batch(0, [[999, 0]], [[0, 0, 1, 0, 0, 5]])  # pixel outside the image
+
+
+def test_golden_cost_fixture(gpu_ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cost_64x48_d16.npz"))
+    for name, sn, lam in (("ss", 0, 0.0), ("cs", 5, 0.3)):
+        gpu_ctx.set_images(g["l"], g["r"])
+        gpu_ctx.build_cost_grd(int(g["max_dis"]), 35, sn, lam)
+        np.testing.assert_array_equal(gpu_ctx.scale_weights(), g[f"{name}_wgt"])
+        for v in (0, 1):
+            np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 5), g[f"{name}_vol0_d5"][v])
+            for s in range(gpu_ctx.levels):
+                assert gpu_ctx.max_cost(v, s) == g[f"{name}_maxc"][v, s]
+            got = gpu_ctx.plane_cost_batch(v, g[f"{name}_v{v}_xy"], g[f"{name}_v{v}_np"])
+            np.testing.assert_array_equal(got, g[f"{name}_v{v}_device"])
+            np.testing.assert_allclose(got, g[f"{name}_v{v}_serial"], rtol=1e-12, atol=0)

@@ -1,0 +1,143 @@
+"""The C oracle against independent re-derivations: scipy for the documented OpenCV contracts, and tests/pyref.py
+(a second restatement of the reference sources in Python) for everything the reference itself defines.
+PARITY UNPINNED: none of this is reference output -- the reference cannot be built in this image."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+import pyref
+from oracle import pyoracle as po
+
+
+def _tiny(w, h, D, seed):
+    from crossscalepatchmatch_amd import synth
+    l, r, _, _ = synth.make_pair(w, h, D, regions=2, seed=seed)
+    return l, r
+
+
+def test_pyrdown_matches_scipy_mirror_convolution():
+    """pyrDown contract: separable [1 4 6 4 1]/16, BORDER_REFLECT_101 (= scipy 'mirror'), (v+128)>>8, ceil(size/2)."""
+    rng = np.random.default_rng(4)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    for (h, w) in ((48, 64), (41, 77), (7, 5), (2, 3), (1, 9), (9, 1)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2, 3), np.uint8)
+        po.lib().csor_pyrdown_bgr8(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        t = ndi.convolve1d(img.astype(np.int64), k, axis=1, mode="mirror")
+        t = ndi.convolve1d(t, k, axis=0, mode="mirror")
+        want = ((t[::2, ::2] + 128) >> 8).astype(np.uint8)
+        np.testing.assert_array_equal(out, want)
+        np.testing.assert_array_equal(out, pyref.pyrdown(img))
+
+
+def test_gray_and_gradient():
+    rng = np.random.default_rng(5)
+    h, w = 9, 13
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    rgb = np.ascontiguousarray(bgr[..., ::-1].astype(np.float64))
+    gray = np.zeros((h, w), np.float32)
+    G = np.zeros((h, w))
+    L = po.lib()
+    L.csor_rgb2gray_f32(rgb.ctypes.data_as(C.POINTER(C.c_double)), w, h, gray.ctypes.data_as(C.POINTER(C.c_float)))
+    L.csor_sobel_x_ks1(gray.ctypes.data_as(C.POINTER(C.c_float)), w, h, G.ctypes.data_as(C.POINTER(C.c_double)))
+    np.testing.assert_array_equal(G, pyref.gray_grad(bgr))
+    assert np.all(G[:, 0] == 0) and np.all(G[:, -1] == 0)  # REFLECT_101: zero at both borders
+    # Sobel ksize=1 == correlate with [-1 0 1], mirror border
+    np.testing.assert_array_equal(G, ndi.correlate1d(gray.astype(np.float64), [-1.0, 0.0, 1.0], axis=1, mode="mirror"))
+    # a constant colour image has gray = that value (0.299f+0.587f+0.114f rounds to 1) and zero gradient
+    flat = np.full((3, 4, 3), 200.0)
+    g2 = np.zeros((3, 4), np.float32)
+    L.csor_rgb2gray_f32(flat.ctypes.data_as(C.POINTER(C.c_double)), 4, 3, g2.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.all(np.abs(g2 - 200.0) < 1e-4)
+
+
+@pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (3, 0.3)])
+def test_volumes_and_max_cost(scale_num, lam):
+    l, r = _tiny(26, 15, 9, 1)
+    pc = po.PlaneCost(l, r, 9, 5, scale_num, lam)
+    ref = pyref.PlaneCost(l, r, 9, 5, scale_num, lam)
+    for s in range(pc.levels):
+        assert pc.dims(s) == ref.dims[s]
+        for v in (0, 1):
+            np.testing.assert_array_equal(pc.image(v, s), ref.img[v][s])
+            np.testing.assert_array_equal(pc.volume(v, s), ref.vol[v][s])
+            assert pc.max_cost(v, s) == ref.max_cost[v][s]
+    # GRD cost is bounded by ALPHA*TAU_CLR + (1-ALPHA)*TAU_GRD = 2.8 and non-negative
+    assert 0.0 <= pc.volume(0, 0).min() and pc.volume(0, 0).max() <= 0.1 * 10.0 + (1 - 0.1) * 2.0
+    # border branch: left view, x < d uses the constant-3 "other" pixel
+    lf = l[..., ::-1].astype(np.float64)
+    G = pyref.gray_grad(l)
+    d, y, x = 5, 3, 2
+    clr = min((abs(lf[y, x, 0] - 3) + abs(lf[y, x, 1] - 3) + abs(lf[y, x, 2] - 3)) * 0.3333333333, 10.0)
+    want = 0.1 * clr + (1 - 0.1) * min(abs(G[y, x] - 3), 2.0)
+    assert pc.volume(0, 0)[d, y, x] == want
+
+
+@pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (3, 0.3), (5, 1.0)])
+def test_get_plane_cost_serial_order(scale_num, lam):
+    l, r = _tiny(30, 22, 10, 2)
+    pc = po.PlaneCost(l, r, 10, 7, scale_num, lam)
+    ref = pyref.PlaneCost(l, r, 10, 7, scale_num, lam)
+    rng = np.random.default_rng(8)
+    for i in range(60):
+        x, y, v = int(rng.integers(0, 30)), int(rng.integers(0, 22)), int(rng.integers(0, 2))
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if i == 0: n = np.array([0.0, 0.0, 1.0])
+        if i == 1: n = np.array([0.6, 0.8, 1e-10]); x, y = 0, 0
+        z = rng.uniform(-3, 14)
+        prm = po.plane_param(n, [x, y, z])
+        np.testing.assert_array_equal(prm, pyref.plane_param(n, [float(x), float(y), z]))
+        got = pc.cost(x, y, n, prm, v, po.SUM_SERIAL)
+        assert got == ref.cost(x, y, n, prm, v), (i, x, y, v)
+        dev = pc.cost(x, y, n, prm, v, po.SUM_DEVICE)
+        assert abs(dev - got) <= 1e-12 * max(1.0, abs(got))  # same terms, other summation order
+
+
+def test_threshold_variant_is_result_preserving():
+    l, r = _tiny(40, 30, 12, 3)
+    pc = po.PlaneCost(l, r, 12, 35, 5, 0.3)
+    rng = np.random.default_rng(9)
+    for i in range(300):
+        x, y, v = int(rng.integers(0, 40)), int(rng.integers(0, 30)), int(rng.integers(0, 2))
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        prm = po.plane_param(n, [x, y, rng.uniform(0, 12)])
+        for order in (po.SUM_SERIAL, po.SUM_DEVICE):
+            full = pc.cost(x, y, n, prm, v, order)
+            for thr in (full * 0.5, full, np.nextafter(full, np.inf), full * 2):
+                c, taps = pc.cost_thresh(x, y, n, prm, v, order, thr)
+                if full >= thr:
+                    assert c == np.inf
+                else:
+                    assert c == full and taps == pc.taps(x, y)
+    # exact tap count: interior pixel of a big-enough level has (2*17+1)^2 taps at level 0
+    assert po.PlaneCost(l, r, 12, 35, 0, 0.0).taps(20, 17) == sum(1 for dy in range(-17, 18) for dx in range(-17, 18)
+                                                                    if 0 <= 20 + dx < 40 and 0 <= 17 + dy < 30)
+
+
+@pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (2, 0.3)])
+def test_whole_patchmatch_against_second_restatement(scale_num, lam):
+    """init + 2 x (spatial raster, view, refine) + PlaneToDisp + PostProcessing on a 14x9 pair, window 5."""
+    l, r = _tiny(14, 9, 6, 4)
+    pc = po.PlaneCost(l, r, 6, 5, scale_num, lam)
+    rpc = pyref.PlaneCost(l, r, 6, 5, scale_num, lam)
+    pm = po.PatchMatch(l, r, 6, 16)
+    ref = pyref.PatchMatch(l, r, 6, 16, seed=77)
+    kw = dict(seed=77, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+    pm.init(pc, **kw); ref.init(rpc)
+    for it in range(2):
+        for phase in ("spatial", "view", "refine"):
+            getattr(pm, phase)(it, pc, **kw); getattr(ref, phase)(it, rpc)
+            for v in (0, 1):
+                P = pm.planes(v)
+                np.testing.assert_array_equal(P[..., 0:3], ref.n[v], err_msg=f"{phase} {it} norm")
+                np.testing.assert_array_equal(P[..., 3:6], ref.p[v], err_msg=f"{phase} {it} point")
+                np.testing.assert_array_equal(P[..., 6:9], ref.prm[v], err_msg=f"{phase} {it} param")
+                np.testing.assert_array_equal(pm.min_cost(v), ref.cost[v], err_msg=f"{phase} {it} cost")
+    pm.plane_to_disp(); ref.plane_to_disp()
+    for v in (0, 1):
+        np.testing.assert_array_equal(pm.dis(v), ref.dis[v])
+    pm.postprocess(); ref.postprocess()
+    for v in (0, 1):
+        np.testing.assert_array_equal(pm.dis(v), ref.dis[v])
