@@ -1,0 +1,30 @@
+// cs_patchmatch.h -- class CSPatchMatch with the reference's public interface (CSPM/cs_patchmatch.h:17-68).
+#pragma once
+#include "commfunc.h"
+#include "plane.h"
+#include "plane_cost/i_plane_cost.h"
+
+#define WMF_GAMMA 10.0
+
+class CSPatchMatch {
+ public:
+  CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_dis, const int &dis_scale);
+  ~CSPatchMatch() {}
+  // init, iter_num x (spatial, view, refinement), PlaneToDisp, optional PostProcessing (cs_patchmatch.cc:51-109).
+  // plane_cost must be a device cost (PreSSPC / PreCSPC): the loop runs on its GPU.
+  void PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp);
+  Mat &dis(const RefView &view) { return dis_[view]; }
+
+  // additions (the reference seeds from time(NULL) and has one schedule)
+  void set_seed(uint64_t seed) { seed_ = seed; }
+  void set_schedule(int schedule, int rb_rounds = 1) { schedule_ = schedule; rb_rounds_ = rb_rounds; }
+  // final plane field of a view, for callers that want sub-pixel disparities
+  void planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const;
+
+ private:
+  Mat img_[kViewNum], dis_[kViewNum];
+  int wid_, hei_, max_dis_, dis_scale_;
+  uint64_t seed_;
+  int schedule_, rb_rounds_;
+  cspm_ctx *last_ctx_;
+};

@@ -1,0 +1,13 @@
+// get_method.h -- name -> method factories with the reference's contract (CSPM/get_method.h:21-67,
+// main.cc:39-55): unknown or unimplemented names yield NULL.
+#pragma once
+#include "ca_method.h"
+#include "cc/grd_cc.h"
+#include "cc_method.h"
+
+inline CCMethod *getCCType(const string &name) {
+  if (name == "GRD") return new GrdCC();
+  return NULL;  // "CEN", "BSM", "CG": no implementation in this build
+}
+inline CCMethod *GetCCType(const string &name) { return getCCType(name); }  // spelling used by main.cc:39
+inline CAMethod *getCAType(const string &) { return NULL; }                 // "GF", "BF", "BOX", "NL", "ST"

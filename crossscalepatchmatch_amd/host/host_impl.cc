@@ -1,0 +1,144 @@
+// host_impl.cc -- GrdCC, DevicePlaneCost (PreSSPC / PreCSPC) and CSPatchMatch above the C ABI of
+// libcspm_hip.so.  No arithmetic of the hot path happens here.
+#include <vector>
+
+#include "../../include/cspm.h"
+#include "cc/grd_cc.h"
+#include "cs_patchmatch.h"
+#include "plane_cost/device_plane_cost.h"
+
+namespace {
+void check(int rc, cspm_ctx *ctx, const char *what) {
+  if (rc != CSPM_OK) throw std::runtime_error(std::string(what) + ": " + cspm_last_error(ctx));
+}
+// CV_64F copy of a Mat with packed rows
+std::vector<double> packed64(const Mat &m) {
+  CV_Assert(m.depth() == CV_64F);
+  const size_t row = (size_t)m.cols * m.channels();
+  std::vector<double> v(row * m.rows);
+  for (int y = 0; y < m.rows; ++y) std::memcpy(&v[y * row], m.ptr<double>(y), row * sizeof(double));
+  return v;
+}
+}  // namespace
+
+// ---------------------------------------------------------------- GrdCC (cc/grd_cc.cpp:60-154)
+void GrdCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int right) {
+  CV_Assert(lImg.type() == CV_64FC3 && rImg.type() == CV_64FC3);  // grd_cc.cpp:63
+  CV_Assert(lImg.rows == rImg.rows && lImg.cols == rImg.cols && maxDis >= 1 && vol);
+  const int h = lImg.rows, w = lImg.cols;
+  std::vector<double> l = packed64(lImg), r = packed64(rImg), out((size_t)maxDis * h * w);
+  check(cspm_grd_build_cv_host(device_, l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "GrdCC");
+  for (int d = 0; d < maxDis; ++d) {
+    if (vol[d].rows != h || vol[d].cols != w || vol[d].type() != CV_64FC1) vol[d].create(h, w, CV_64FC1);
+    for (int y = 0; y < h; ++y) std::memcpy(vol[d].ptr<double>(y), &out[((size_t)d * h + y) * w], sizeof(double) * w);
+  }
+}
+void GrdCC::buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol) { build(lImg, rImg, maxDis, costVol, 0); }
+void GrdCC::buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol) { build(lImg, rImg, maxDis, rCostVol, 1); }
+
+// ---------------------------------------------------------------- PreSSPC / PreCSPC
+int DevicePlaneCost::device = 0;
+
+DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num,
+                                 CCMethod *cc_method, double reg_lambda)
+    : ctx_(NULL) {
+  CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // pre_cs_pc.cc:25, pre_ss_pc.cc:24
+  CV_Assert(l_img.rows == r_img.rows && l_img.cols == r_img.cols);
+  if (!cc_method) throw std::runtime_error("PreSSPC/PreCSPC: NULL CCMethod (unknown --cc_name)");  // the reference dereferences it
+  check(cspm_create(&ctx_, device), NULL, "cspm_create");
+  const Mat l = l_img.clone(), r = r_img.clone();  // packed rows
+  check(cspm_set_images(ctx_, l.data, r.data, l.cols, l.rows, l.step), ctx_, "cspm_set_images");
+  if (dynamic_cast<GrdCC *>(cc_method)) {
+    // the known cost function: pyramid, gradients, max_cost, scale weights all on the device
+    check(cspm_build_cost_grd(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_grd");
+    return;
+  }
+  // a foreign CCMethod: let it fill host volumes level by level exactly as pre_cs_pc.cc:57-74 does
+  check(cspm_begin_cost(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_begin_cost");
+  const int levels = cspm_get_levels(ctx_);
+  for (int s = 0; s < levels; ++s)
+    for (int v = 0; v < kViewNum; ++v) upload_foreign(cc_method, v, s);
+  check(cspm_finish_cost(ctx_), ctx_, "cspm_finish_cost");
+}
+
+void DevicePlaneCost::upload_foreign(CCMethod *cc, int view, int level) {
+  int w, h, D;
+  check(cspm_get_level_dims(ctx_, level, &w, &h, &D), ctx_, "cspm_get_level_dims");
+  Mat rgb[2];
+  for (int v = 0; v < 2; ++v) {  // cvtColor(BGR2RGB) + convertTo(CV_64F), pre_cs_pc.cc:60-64
+    std::vector<unsigned char> bgr((size_t)w * h * 3);
+    check(cspm_get_level_image(ctx_, v, level, bgr.data()), ctx_, "cspm_get_level_image");
+    rgb[v].create(h, w, CV_64FC3);
+    for (int y = 0; y < h; ++y) {
+      double *o = rgb[v].ptr<double>(y);
+      for (int x = 0; x < w; ++x)
+        for (int c = 0; c < 3; ++c) o[3 * x + c] = bgr[((size_t)y * w + x) * 3 + (2 - c)];
+    }
+  }
+  std::vector<Mat> vol(D + 1);
+  for (int d = 0; d <= D; ++d) vol[d] = Mat::zeros(h, w, CV_64FC1);  // pre_cs_pc.cc:50-53
+  if (view == kLeft) cc->buildCV(rgb[0], rgb[1], D + 1, vol.data());
+  else cc->buildRightCV(rgb[0], rgb[1], D + 1, vol.data());
+  for (int d = 0; d <= D; ++d)
+    check(cspm_upload_cost_slab(ctx_, view, level, d, vol[d].ptr<double>(0), vol[d].step / sizeof(double)), ctx_, "cspm_upload_cost_slab");
+}
+
+DevicePlaneCost::~DevicePlaneCost() { cspm_destroy(ctx_); }
+
+double DevicePlaneCost::GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const {
+  const int xy[2] = {ref_x, ref_y};
+  const Vec3d n = plane.norm(), p = plane.param();
+  const double np[6] = {n[0], n[1], n[2], p[0], p[1], p[2]};
+  double cost = 0.0;
+  check(cspm_plane_cost_batch(ctx_, view, 1, xy, np, &cost), ctx_, "cspm_plane_cost_batch");
+  return cost;
+}
+
+// ---------------------------------------------------------------- CSPatchMatch (cs_patchmatch.cc:3-109)
+CSPatchMatch::CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_dis, const int &dis_scale)
+    : max_dis_(max_dis), dis_scale_(dis_scale), seed_(12345), schedule_(CSPM_SCHED_RASTER), rb_rounds_(1), last_ctx_(NULL) {
+  CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // cs_patchmatch.cc:8
+  img_[kLeft] = l_img.clone();
+  img_[kRight] = r_img.clone();
+  wid_ = l_img.cols;
+  hei_ = l_img.rows;
+  for (int v = 0; v < kViewNum; ++v) dis_[v] = Mat::zeros(hei_, wid_, CV_8UC1);
+}
+
+void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp) {
+  const IDevicePlaneCost *dev = dynamic_cast<const IDevicePlaneCost *>(plane_cost);
+  if (!dev)
+    throw std::runtime_error("CSPatchMatch::PatchMatch: the plane cost is not device-resident. This build runs PatchMatch on the "
+                             "GPU only; wrap a foreign cost function as a CCMethod (PreSSPC/PreCSPC upload its volumes).");
+  cspm_ctx *ctx = dev->device_ctx();
+  cspm_pm_params p;
+  cspm_pm_default_params(&p);
+  p.seed = seed_;
+  p.schedule = schedule_;
+  p.rb_rounds = rb_rounds_;
+  check(cspm_patchmatch(ctx, iter_num, &p), ctx, "cspm_patchmatch");
+  if (use_pp) {  // PostProcessing (cs_patchmatch.cc:105-107)
+    check(cspm_postprocess(ctx, dis_scale_, dis_[kLeft].data, dis_[kRight].data, dis_[kLeft].step), ctx, "cspm_postprocess");
+  } else {       // PlaneToDisp (cs_patchmatch.cc:103)
+    for (int v = 0; v < kViewNum; ++v)
+      check(cspm_get_disparity_u8(ctx, v, dis_scale_, dis_[v].data, dis_[v].step), ctx, "cspm_get_disparity_u8");
+  }
+  last_ctx_ = ctx;
+}
+
+void CSPatchMatch::planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const {
+  if (!last_ctx_) throw std::runtime_error("CSPatchMatch::planes before PatchMatch");
+  const size_t n = (size_t)wid_ * hei_;
+  std::vector<double> np(6 * n), cost(n);
+  check(cspm_get_planes(last_ctx_, view, np.data(), cost.data()), last_ctx_, "cspm_get_planes");
+  if (out) {
+    out->resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      Plane pl;
+      pl.set_norm(Point3d(np[6 * i], np[6 * i + 1], np[6 * i + 2]));
+      pl.set_param(Vec3d(np[6 * i + 3], np[6 * i + 4], np[6 * i + 5]));
+      (*out)[i] = pl;
+    }
+  }
+  if (min_cost) *min_cost = cost;
+}

@@ -1,0 +1,20 @@
+// device_plane_cost.h -- common implementation of PreSSPC / PreCSPC above the C ABI (include/cspm.h).
+#pragma once
+#include "../cc_method.h"
+#include "i_plane_cost.h"
+
+class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
+ public:
+  // scale_num == 0: PreSSPC (pre_ss_pc.cc:12-65); >= 1: PreCSPC (pre_cs_pc.cc:12-115).  cc_method is borrowed.
+  DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, CCMethod *cc_method,
+                  double reg_lambda);
+  ~DevicePlaneCost();
+  virtual double GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const;
+  virtual cspm_ctx *device_ctx() const { return ctx_; }
+  static int device;  // GPU used by objects constructed from now on (the CLI's --device)
+
+ private:
+  DevicePlaneCost(const DevicePlaneCost &);
+  void upload_foreign(CCMethod *cc, int view, int level);
+  cspm_ctx *ctx_;
+};

@@ -1,0 +1,76 @@
+"""The C++ host layer (crossscalepatchmatch_amd/host): image I/O + gflags-compatible parser on CPU; the
+reference-style command line end to end on the GPU (-m gpu)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pngio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "crossscalepatchmatch_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def io_check(tmp_path_factory):
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "host_io_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "helpers", "host_io_check.cc"),
+                           os.path.join(HOST, "image_io.cc"), "-lz"])
+    return exe
+
+
+@pytest.mark.parametrize("filt", [0, 1, 2])
+def test_png_and_pnm_roundtrip_and_flags(io_check, tmp_path, filt):
+    rng = np.random.default_rng(filt)
+    rgb = rng.integers(0, 256, (13, 17, 3)).astype(np.uint8)
+    src = str(tmp_path / "in.png")
+    pngio.write_png(src, rgb, filter_type=filt)
+    for ext in ("png", "ppm"):
+        oc, og = str(tmp_path / f"c.{ext}"), str(tmp_path / ("g.png" if ext == "png" else "g.pgm"))
+        out = subprocess.check_output([io_check, src, oc, og, "--l_img_file=a b.png", "--max_dis", "60", "--use_cs", "--nouse_pp",
+                                       "-reg_lambda=0.3"]).decode().strip()
+        assert out == "a b.png|60|1|0|0.29999999999999999"
+        rd = pngio.read_png if ext == "png" else pngio.read_pnm
+        np.testing.assert_array_equal(rd(oc), rgb)
+        np.testing.assert_array_equal(rd(og), rgb[..., 1])
+    # a gray PNG and a PGM load as 3 equal channels (CV_LOAD_IMAGE_COLOR)
+    pngio.write_png(str(tmp_path / "gray.png"), rgb[..., 0])
+    pngio.write_pnm(str(tmp_path / "gray.pgm"), rgb[..., 0])
+    for name in ("gray.png", "gray.pgm"):
+        subprocess.check_call([io_check, str(tmp_path / name), str(tmp_path / "o.ppm"), str(tmp_path / "o.pgm")], stdout=subprocess.DEVNULL)
+        np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "o.pgm")), rgb[..., 0])
+    assert subprocess.call([io_check, str(tmp_path / "missing.png"), "a", "b"]) == 3
+
+
+def test_unknown_flag_is_rejected(io_check, tmp_path):
+    src = str(tmp_path / "in.pgm")
+    pngio.write_pnm(src, np.zeros((2, 2), np.uint8))
+    p = subprocess.run([io_check, src, str(tmp_path / "a.pgm"), str(tmp_path / "b.pgm"), "--no_such_flag=1"], capture_output=True)
+    assert p.returncode == 1 and b"unknown command line flag" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_cs,use_pp", [(False, False), (True, True)])
+def test_cli_matches_the_c_abi_path(gpu_ctx, mid_pair, tmp_path, use_cs, use_pp):
+    """cspm_main with the reference's flags (main.cc:23-34) == the same run through the C ABI."""
+    exe = os.path.join(ROOT, "crossscalepatchmatch_amd", "cspm_main")
+    assert os.path.exists(exe), "build the host layer: python -c 'import __graft_entry__ as g; g.build()'"
+    l, r = mid_pair["l"], mid_pair["r"]
+    pngio.write_png(str(tmp_path / "l.png"), l[..., ::-1])  # files are RGB, imread returns BGR
+    pngio.write_png(str(tmp_path / "r.png"), r[..., ::-1])
+    args = [exe, f"--l_img_file={tmp_path}/l.png", f"--r_img_file={tmp_path}/r.png", f"--l_dis_file={tmp_path}/ld.png",
+            f"--r_dis_file={tmp_path}/rd.png", "--max_dis=16", "--dis_scale=4", '--cc_name="GRD"', f"--use_cs={'true' if use_cs else 'false'}",
+            f"--use_pp={'true' if use_pp else 'false'}", "--reg_lambda=0.3", "--seed=777"]
+    out = subprocess.check_output(args).decode()
+    assert "Total Time:" in out
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(16, 35, 5 if use_cs else 0, 0.3)
+    gpu_ctx.patchmatch(3, seed=777, schedule=0)
+    want = gpu_ctx.postprocess(4) if use_pp else (gpu_ctx.disparity_u8(0, 4), gpu_ctx.disparity_u8(1, 4))
+    np.testing.assert_array_equal(pngio.read_png(str(tmp_path / "ld.png")), want[0])
+    np.testing.assert_array_equal(pngio.read_png(str(tmp_path / "rd.png")), want[1])
+    # unknown cost name: error exit instead of the reference's NULL dereference
+    assert subprocess.call(args[:7] + ['--cc_name="CEN"'], stdout=subprocess.DEVNULL) == 1
