@@ -1,0 +1,134 @@
+"""Full-size runs (BASELINE.json configs) on the GPU: the oracle cannot do a whole KITTI-size pair in seconds,
+so parity at these sizes is checked (a) exactly, on sampled plane evaluations against the oracle, and (b) through
+size-independent properties of the algorithm: determinism, monotone costs, stored cost == re-evaluated cost,
+early exit on/off and fused/volume cost sources giving identical plane fields."""
+import numpy as np
+import pytest
+
+from conftest import random_planes
+from crossscalepatchmatch_amd import synth
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3():
+    cfg, l, r, gl, gr = synth.make_config("C3")
+    return cfg, l, r, gl, gr
+
+
+def test_c3_sampled_plane_costs_equal_the_oracle(gpu_ctx, c3):
+    cfg, l, r, _, _ = c3
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])  # ~1.1 GB of f64 volumes on the host
+    assert [gpu_ctx.level_dims(s) for s in range(5)] == [(1242, 375, 128), (621, 188, 64), (311, 94, 32), (156, 47, 16), (78, 24, 8)]
+    np.testing.assert_array_equal(gpu_ctx.scale_weights(), pc.scale_wgt())
+    rng = np.random.default_rng(17)
+    for v in (0, 1):
+        for s in range(5):
+            assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
+        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 77), pc.volume(v, 0)[77])
+        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 2, 32), pc.volume(v, 2)[32])
+        xy, norm, point, param = random_planes(rng, 400, cfg["w"], cfg["h"], cfg["max_dis"])
+        got = gpu_ctx.plane_cost_batch(v, xy, np.concatenate([norm, param], 1))
+        want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], v, po.SUM_DEVICE) for i in range(len(xy))])
+        np.testing.assert_array_equal(got, want)
+
+
+def _state(ctx):
+    return [ctx.get_planes(v) for v in (0, 1)]
+
+
+def test_c3_properties(gpu_ctx, c3):
+    cfg, l, r, gl, gr = c3
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    kw = dict(seed=2024, schedule=0)
+    # monotone: no phase may increase any pixel's cost
+    gpu_ctx.pm_init(**kw)
+    prev = [c for _, c in _state(gpu_ctx)]
+    for phase in ("pm_spatial", "pm_view", "pm_refine"):
+        getattr(gpu_ctx, phase)(0, **kw)
+        cur = [c for _, c in _state(gpu_ctx)]
+        for v in (0, 1):
+            assert np.all(cur[v] <= prev[v]), phase
+            assert np.any(cur[v] < prev[v]), phase
+        prev = cur
+    # whole run, twice: deterministic
+    gpu_ctx.patchmatch(3, **kw)
+    a = _state(gpu_ctx)
+    dis_a = [gpu_ctx.disparity_u8(v, cfg["dis_scale"]) for v in (0, 1)]
+    gpu_ctx.patchmatch(3, **kw)
+    b = _state(gpu_ctx)
+    for v in (0, 1):
+        np.testing.assert_array_equal(a[v][0], b[v][0])
+        np.testing.assert_array_equal(a[v][1], b[v][1])
+    # stored min_cost == cost of the stored plane, re-evaluated (no early exit), on a sample of pixels
+    rng = np.random.default_rng(3)
+    for v in (0, 1):
+        npar, cost = a[v]
+        ys, xs = rng.integers(0, cfg["h"], 3000), rng.integers(0, cfg["w"], 3000)
+        got = gpu_ctx.plane_cost_batch(v, np.stack([xs, ys], 1), npar[ys, xs])
+        np.testing.assert_array_equal(got, cost[ys, xs])
+        # unit normals, parameters consistent with normals
+        n = npar[..., :3]
+        np.testing.assert_allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-9)
+        # 8-bit map == saturate(round_half_even(d * dis_scale))
+        d = gpu_ctx.disparity_f64(v)
+        np.testing.assert_array_equal(dis_a[v], np.clip(np.rint(d * cfg["dis_scale"]), 0, 255).astype(np.uint8))
+    # early exit off: identical plane field
+    gpu_ctx.patchmatch(3, early_exit=0, **kw)
+    c = _state(gpu_ctx)
+    for v in (0, 1):
+        np.testing.assert_array_equal(a[v][0], c[v][0])
+        np.testing.assert_array_equal(a[v][1], c[v][1])
+    # the result is a disparity map of the scene, not noise (noise floor of this synthetic pair is ~6 %)
+    assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.12
+    assert synth.bad_fraction(gpu_ctx.disparity_f64(1), gr, 2.0) < 0.12
+    # materialised f64 cost volumes (the reference's data flow) give the same plane field as fused cells
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=True)
+    gpu_ctx.patchmatch(3, **kw)
+    e = _state(gpu_ctx)
+    for v in (0, 1):
+        np.testing.assert_array_equal(a[v][0], e[v][0])
+        np.testing.assert_array_equal(a[v][1], e[v][1])
+    gpu_ctx.build_cost_grd(16, 35, 0, 0.0)  # drop the 1.1 GB volumes
+
+
+def test_c1_single_scale_config(gpu_ctx):
+    """BASELINE.json configs[0]: 450x375, max_dis=60, GRD, use_cs=false, use_pp=false -- sampled exact costs + properties."""
+    cfg, l, r, gl, _ = synth.make_config("C1")
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, 0, 0.0)
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, 0, 0.0)
+    rng = np.random.default_rng(5)
+    xy, norm, point, param = random_planes(rng, 500, cfg["w"], cfg["h"], cfg["max_dis"])
+    got = gpu_ctx.plane_cost_batch(0, xy, np.concatenate([norm, param], 1))
+    want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 0, po.SUM_DEVICE) for i in range(500)])
+    np.testing.assert_array_equal(got, want)
+    gpu_ctx.patchmatch(3, seed=1, schedule=0)
+    npar, cost = gpu_ctx.get_planes(0)
+    ys, xs = rng.integers(0, cfg["h"], 1000), rng.integers(0, cfg["w"], 1000)
+    want = np.array([pc.cost(xs[i], ys[i], npar[ys[i], xs[i], :3], npar[ys[i], xs[i], 3:], 0, po.SUM_DEVICE) for i in range(1000)])
+    np.testing.assert_array_equal(cost[ys, xs], want)  # the oracle agrees with every stored cost it is asked about
+    assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.25
+
+
+def test_c5_full_resolution_runs(gpu_ctx):
+    """BASELINE.json configs[4]: 3000x2000, max_dis=256, cross-scale, use_pp=true.  f64 volumes would be 28 GB; the
+    fused cost needs ~0.3 GB.  One iteration + post-processing; self-consistency of stored costs."""
+    cfg, l, r, gl, _ = synth.make_config("C5")
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    assert gpu_ctx.level_dims(4) == (188, 125, 16)
+    gpu_ctx.patchmatch(1, seed=7, schedule=0)
+    npar, cost = gpu_ctx.get_planes(0)
+    rng = np.random.default_rng(9)
+    ys, xs = rng.integers(0, cfg["h"], 2000), rng.integers(0, cfg["w"], 2000)
+    got = gpu_ctx.plane_cost_batch(0, np.stack([xs, ys], 1), npar[ys, xs])
+    np.testing.assert_array_equal(got, cost[ys, xs])
+    lo, ro = gpu_ctx.postprocess(cfg["dis_scale"])
+    assert lo.shape == (2000, 3000) and lo.max() <= 255
+    gpu_ctx.set_images(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8))  # release the big buffers
