@@ -213,7 +213,7 @@ int scale_weights(int S, double lambda, double *w) {
 // except gradients / volume contents / max_cost)
 int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol) {
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
-  if (max_dis < 1 || wnd_size < 1 || wnd_size > 127 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
+  if (max_dis < 1 || wnd_size < 1 || wnd_size > 45 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
     return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
   free_cost(c);
   Cost &cd = c->cost;
@@ -223,9 +223,8 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   cd.n = 2 * cd.half + 1;
   cd.T = cd.n * cd.n;
   cd.groups = (cd.T + kWave - 1) / kWave;
-  cd.inv_n = 1.0f / (float)cd.n;
-  for (int t = 0; t < ((cd.groups + 3) / 4) * 256; ++t)  // the kernels' tap -> (dy,dx) formula must be exact
-    if ((int)(((float)t + 0.5f) * cd.inv_n) != t / cd.n) return fail(c, CSPM_ERR_ARG, "window too large for the float tap decode");
+  cd.rounds = (cd.groups + 3) / 4;
+  if (cd.rounds > kMaxRounds) return fail(c, CSPM_ERR_ARG, "wnd_size too large (the tap decode table holds 2048 taps: wnd_size <= 45)");
   c->max_dis = max_dis;
   c->wnd = wnd_size;
   int rc;
@@ -279,6 +278,14 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   if ((rc = dalloc(c, &c->d_lut, 2 * kLutSize, &c->cost_allocs))) return rc;
   c->d_lut_a = c->d_lut + kLutSize;
   if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
+  {  // tap decode table: t -> (dx, dy) of the linearised window, bit 31 marks the padding taps t >= T
+    std::vector<uint32_t> dec((size_t)cd.rounds * 256);
+    for (int t = 0; t < cd.rounds * 256; ++t) dec[t] = t < cd.T ? (uint32_t)((t % cd.n) | ((t / cd.n) << 8)) : 0x80000000u;
+    uint32_t *d_dec;
+    if ((rc = dalloc(c, &d_dec, dec.size(), &c->cost_allocs))) return rc;
+    HIPCHK(c, hipMemcpy(d_dec, dec.data(), dec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    cd.dec = d_dec;
+  }
   if ((rc = dalloc(c, &c->d_maxkeys, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));

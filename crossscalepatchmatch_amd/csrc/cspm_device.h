@@ -16,6 +16,7 @@ constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_
 constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
 constexpr int kLutZero = 767;              // entry forced to 0.0: masked taps read it, so they add wgt*tmp = +0.0
 constexpr int kTabSize = 128;              // per-wave tables a*qx / b*qy+c, one entry per window column / row
+constexpr int kMaxRounds = 8;              // tap decode table in LDS: up to 2048 taps (window <= 45x45)
 constexpr int kWave = 64;
 constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup
 constexpr int kDiagBlock = 512;            // raster-sweep kernel: 8 waves cooperate on one pixel (2 candidates x 4 slot blocks)
@@ -25,15 +26,14 @@ constexpr uint32_t kBorderPix = 0x00030303u;  // BORDER_THRES in B, G and R (cc/
 // Images are stored PADDED: row stride Wp = W + 2*pad, image column x at index pad + x, pad = D + 2.
 // Pad cells hold the GRD border constant (BORDER_THRES = 3 for every channel and for the gradient,
 // cc/grd_cc.h:6), so the fused cost needs no border branch (cc/grd_cc.cpp:88-100, 134-147).
-// The PatchMatch kernels read the array-of-structs `px`: one 16-byte element per pixel = packed colour
-// + x-gradient, so one dwordx4 load fetches everything a tap needs of a pixel (the L1 address path
-// charges a wave64 load ~16 cycles whatever its width).
-struct PixG {
+// The PatchMatch kernels read the array-of-structs `px`: one 12-byte element per pixel = packed colour
+// + x-gradient, so one dwordx3 load fetches everything a tap needs of a pixel (the L1 address path
+// charges a wave64 load ~16 cycles whatever its width; the L1 return path charges bytes).
+struct __attribute__((packed, aligned(4))) PixG {
   uint32_t pix;  // B | G<<8 | R<<16 (byte 3 = 0)
-  uint32_t spare;
   double g;      // x-gradient of the f32 gray image (grd_cc.cpp:70-77); GRD only
 };
-static_assert(sizeof(PixG) == 16, "PixG must be 16 bytes");
+static_assert(sizeof(PixG) == 12, "PixG must be 12 bytes");
 
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
@@ -53,7 +53,8 @@ struct Cost {
   int n;       // 2*half+1
   int T;       // n*n taps
   int groups;  // ceil(T/64)
-  float inv_n; // 1.0f/n: dy = (int)(((float)t + 0.5f) * inv_n), verified exhaustively on the host
+  int rounds;  // ceil(groups/4): taps are processed 256 at a time
+  const uint32_t *dec; // tap decode table, rounds*256 entries: dx | dy<<8, bit 31 set for t >= T
   int early_ok;           // all scale weights and max_costs are >= 0
   const double *lut;      // lookup_exp_[i] = exp(-i/10), host-computed, kLutSize entries
   const double *lut_a;    // GRD colour term ALPHA*min(i*0.3333333333, TAU_CLR) (grd_cc.cpp:8-18), kLutSize entries

@@ -30,9 +30,10 @@ namespace cspm {
 // IPlaneCost::GetPlaneCost  (PreSSPC: pre_ss_pc.cc:74-118, PreCSPC: pre_cs_pc.cc:133-188)
 // ------------------------------------------------------------------------------------------------
 struct Luts {
-  const double *w;  // exp(-i/10), entry kLutZero = 0                 (pre_cs_pc.cc:111-114)
-  const double *a;  // ALPHA*min(i*0.3333333333,TAU_CLR)               (grd_cc.cpp:8-18), fused path only
-  double *tab;      // this wave's tables: tab[dx] = a*qx, tab[kTabSize+dy] = b*qy+c
+  const double *w;      // exp(-i/10), entry kLutZero = 0                 (pre_cs_pc.cc:111-114)
+  const double *a;      // ALPHA*min(i*0.3333333333,TAU_CLR)               (grd_cc.cpp:8-18), fused path only
+  double *tab;          // this wave's tables: tab[dx] = a*qx, tab[kTabSize+dy] = b*qy+c
+  const uint32_t *dec;  // tap t -> dx | dy<<8 | (t>=T)<<31
 };
 
 // everything one level needs, wave-uniform
@@ -53,12 +54,13 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ uint4 ld16(const PixG *base, unsigned idx) {  // 32-bit offset: saddr + voffset addressing
-  uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + (size_t)(idx << 4));
-  asm volatile("" ::"v"(v.y));  // demand the spare dword: keeps ONE global_load_dwordx4 instead of dword + dwordx2
-  return v;
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+// one global_load_dwordx3 with a 32-bit byte offset (saddr + voffset addressing, no 64-bit address math)
+__device__ __forceinline__ u32x3 ld12(const PixG *base, int idx) {
+  return *reinterpret_cast<const u32x3_a4 *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)__mul24(idx, 12));
 }
-__device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double((int)v.w, (int)v.z); }
+__device__ __forceinline__ double g_of(const u32x3 &v) { return __hiloint2double((int)v.z, (int)v.y); }
 
 // Prepare one level for this wave: uniform arguments plus the two per-wave tables
 //   tab[dx]          = plane_a * q_x            (the product of pre_cs_pc.cc:165)
@@ -92,7 +94,7 @@ __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut,
 // myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
 // arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
 // TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
-__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const uint4 &o) {
+__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const u32x3 &o) {
   const int sad = (int)__builtin_amdgcn_sad_u8(Iq, o.x, 0u);
   const double grdDiff = __builtin_fmin(fabs(Gq - g_of(o)), 2.0);  // TAU_GRD
   return lut.a[sad] + (1 - 0.1) * grdDiff;                         // ALPHA*clrDiff + (1-ALPHA)*grdDiff
@@ -114,12 +116,12 @@ template <bool FUSED>
 __device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
   const int ocen = A.ocen, lutzero = kLutZero, one = 1;
   const double maxc = A.maxc;
-  const int dy = (int)(((float)t + 0.5f) * cd.inv_n);
-  const int dx = t - __mul24(dy, cd.n);  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
-  const bool ok = (t < cd.T) & ((unsigned)(A.oy0 + dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + dx) < (unsigned)A.W);
-  const int o0 = A.obase + __mul24(dy, A.Wp) + dx;
+  const int dec = (int)lut.dec[t];
+  const int dx = dec & 255, dy = (dec >> 8) & 255;
+  const bool ok = (dec >= 0) & ((unsigned)(A.oy0 + dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + dx) < (unsigned)A.W);
+  const int o0 = A.obase + __mul24(dy, A.Wp) + dx;  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
   const int o = ok ? o0 : ocen;
-  const uint4 P = ld16(A.px, (unsigned)o);
+  const u32x3 P = ld12(A.px, o);
   const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, P.x, 0u);  // |dB|+|dG|+|dR|  (:161-163)
   const int sum = ok ? sum0 : lutzero;
   const double wgt = lut.w[sum];                                 // :164
@@ -134,10 +136,11 @@ __device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, c
   if (FUSED) {
     const double Gq = g_of(P);
     const int of = o + __mul24(A.dir, f);
-    c0 = grd_cell(lut, P.x, Gq, ld16(A.opx, (unsigned)of));
-    c1 = grd_cell(lut, P.x, Gq, ld16(A.opx, (unsigned)(of + A.dir)));
+    c0 = grd_cell(lut, P.x, Gq, ld12(A.opx, of));
+    c1 = grd_cell(lut, P.x, Gq, ld12(A.opx, of + A.dir));
   } else {
-    const int dyc = ok ? dy : cd.half, dxc = ok ? dx : cd.half;
+    const int hh = cd.half;
+    const int dyc = ok ? dy : hh, dxc = ok ? dx : hh;
     const double *p = A.vol + (size_t)f * A.slab + (size_t)(A.oy0 + dyc) * A.W + (A.ox0 + dxc);
     c0 = p[0];
     c1 = p[A.slab];
@@ -170,7 +173,7 @@ template <bool FUSED>
 __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A, const Luts &lut, double base, double mul,
                                              double thresh, bool use_thresh, int lane) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  const int rounds = (cd.groups + 3) / 4;
+  const int rounds = cd.rounds;
   // exit when base + S*mul >= thresh, S >= lb: implied by lb > (thresh-base)/mul * (1+1e-6); the margin
   // covers the roundings of this expression and of the float conversion (mul == 0 gives inf/NaN: no exit)
   const float need = use_thresh ? (float)(((thresh - base) / mul) * 1.000001) : 0.0f;
@@ -203,9 +206,16 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
   double cost = 0.0;
   double cur_disp = pa * (double)x + pb * (double)y + pc;  // pre_cs_pc.cc:139-140
   int cur_x = x, cur_y = y;
+  // Plane(org_norm, Point3d(cur_x,cur_y,cur_disp)).param() (:144-149): a and b depend on the normal only, so
+  // they are the same bits at every level; c is re-derived per level
+  double denom = fmax(fabs(nz), kDoubleEps);
+  if (nz < 0.0) denom = -denom;
+  const double a = -nx / denom, b = -ny / denom;
   for (int s = 0; s < cd.levels; ++s) {
-    double a, b, c;
-    plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
+    double dot = nx * (double)cur_x;
+    dot += ny * (double)cur_y;
+    dot += nz * cur_disp;
+    const double c = dot / denom;
     const double wgt = cd.lv[s].wgt;
     const LevelArgs A = make_level(cd, lut, s, view, cur_x, cur_y, a, b, c, lane);
     const double sc = level_cost<FUSED>(cd, A, lut, cost, wgt, thresh, use_thresh, lane);
@@ -223,6 +233,7 @@ struct LutMem {
   double w[kLutSize];
   double a[kLutSize];
   double tab[WAVES][2 * kTabSize];
+  uint32_t dec[kMaxRounds * 256];
 };
 template <int WAVES>
 __device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem<WAVES> &m) {
@@ -231,9 +242,10 @@ __device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem<WAVES> &m) {
     m.a[i] = cd.lut_a[i];
   }
   for (int i = threadIdx.x; i < WAVES * 2 * kTabSize; i += blockDim.x) (&m.tab[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < cd.rounds * 256; i += blockDim.x) m.dec[i] = cd.dec[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  return Luts{m.w, m.a, m.tab[wave]};
+  return Luts{m.w, m.a, m.tab[wave], m.dec};
 }
 
 // Work item (candidate) index of this wave.  Blocks are dealt round-robin to the 8 XCDs; give XCD k
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int
       if (CS) plane_param(c.nx, c.ny, c.nz, (double)cur_x, (double)cur_y, cur_disp, pa, pb, pc);
       const LevelArgs A = make_level(cd, lut, s, v, cur_x, cur_y, pa, pb, pc, lane);
       double acc = 0.0;
-      const int rounds = (cd.groups + 3) / 4;
+      const int rounds = cd.rounds;
       int i = 0;
       for (; i + 5 <= rounds; i += 5) {  // 5 independent taps per trip: their loads are issued together
         const int t = i * 256 + blk * 64 + lane;
@@ -682,7 +694,6 @@ __global__ void k_make_aos(const uint32_t *__restrict__ pix, const double *__res
   if (i >= n) return;
   PixG e;
   e.pix = pix[i];
-  e.spare = 0u;
   e.g = grd ? grd[i] : 0.0;
   out[i] = e;
 }

@@ -78,7 +78,7 @@ def test_plane_cost_batch(gpu_ctx, request, pairname, name, scale_num, lam, volu
 
 def test_small_window(gpu_ctx, small_pair):
     """wnd_size is a constructor argument (pre_ss_pc.h:20-22); 35 is only main.cc's constant."""
-    for wnd in (1, 3, 9, 35, 41):
+    for wnd in (1, 3, 9, 35, 41, 45):
         pc = _build(gpu_ctx, small_pair, 3, 0.3, wnd)
         rng = np.random.default_rng(wnd)
         xy, norm, point, param = random_planes(rng, 64, small_pair["w"], small_pair["h"], small_pair["max_dis"])
