@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--rb-rounds", type=int, default=1)
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--volumes", action="store_true", help="materialise f64 cost volumes (reference data flow) instead of fused cells")
+    ap.add_argument("--raster-launches", action="store_true", help="raster sweep as one launch per anti-diagonal instead of the persistent kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket launches with hipEvents")
     args = ap.parse_args()
@@ -87,6 +88,8 @@ def main():
     d_r = torch.from_numpy(r).to(dev)
     d_out = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
     ctx = cs.StereoContext(local_rank)
+    from crossscalepatchmatch_amd import capi
+    ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
     sched = cs.SCHED_RASTER if args.schedule == "raster" else cs.SCHED_REDBLACK
     pm_kw = dict(seed=12345, schedule=sched, rb_rounds=args.rb_rounds, rb_neighbours=4, early_exit=0 if args.no_early_exit else 1)
 
@@ -131,7 +134,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w}x{h} max_dis={cfg['max_dis']} GRD scale_num={cfg['scale_num']} "
                                    f"reg_lambda={cfg['reg_lambda']} wnd=35 iters=3 (BASELINE.json configs[2] when C3)",
-                       "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule, "rb_rounds": args.rb_rounds, "early_exit": not args.no_early_exit,
+                       "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule, "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds, "early_exit": not args.no_early_exit,
                        "pairs_per_gpu": args.steps, "parallelism": f"{world} independent pair stream(s), one per GPU"},
         }
         ref = timing["refine"]

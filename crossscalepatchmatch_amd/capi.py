@@ -15,6 +15,7 @@ K_GRD, K_INIT, K_SPATIAL, K_VIEW, K_REFINE, K_MISC = range(6)
 K_NAMES = ["grd", "init", "spatial", "view", "refine", "misc"]
 MAX_LEVELS = 8
 OPT_GRD_VOLUMES = 1
+OPT_RASTER_LAUNCHES = 2
 
 # every symbol include/cspm.h declares
 SYMBOLS = [

@@ -51,6 +51,11 @@ struct cspm_ctx {
   ViewCand vc{nullptr, nullptr, nullptr};
   uint8_t *d_dis[2] = {nullptr, nullptr};
   int *d_valid[2] = {nullptr, nullptr};
+  // persistent raster sweep (k_spatial_sweep)
+  unsigned int *d_sweep_ctrl = nullptr, *d_sweep_done = nullptr, *d_sweep_start = nullptr;
+  unsigned int sweep_epoch = 0;
+  long long opt_raster_launches = 0;  // CSPM_OPT_RASTER_LAUNCHES
+  bool sweep_pending = false;         // a sweep's error word has not been checked yet
   // timing
   bool timing = false;
   std::vector<TimingRec> recs;
@@ -157,6 +162,10 @@ void free_field(cspm_ctx *c) {
     c->d_dis[v] = nullptr;
     c->d_valid[v] = nullptr;
   }
+  if (c->d_sweep_ctrl) (void)hipFree(c->d_sweep_ctrl);
+  if (c->d_sweep_done) (void)hipFree(c->d_sweep_done);
+  if (c->d_sweep_start) (void)hipFree(c->d_sweep_start);
+  c->d_sweep_ctrl = c->d_sweep_done = c->d_sweep_start = nullptr;
   c->field_mem = nullptr;
   c->vc = ViewCand{nullptr, nullptr, nullptr};
   c->field_alloc = false;
@@ -330,6 +339,21 @@ int ensure_field(cspm_ctx *c) {
     if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
   }
+  // persistent sweep state: control words, per-pixel done epochs (zero = never), diagonal start table
+  if ((rc = dalloc(c, &c->d_sweep_ctrl, 2, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->d_sweep_done, 2 * n, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_done, 0, sizeof(unsigned int) * 2 * n, c->stream));
+  c->sweep_epoch = 0;
+  {
+    const int nd = c->W + c->H - 1;
+    std::vector<unsigned int> start(nd + 1, 0);
+    for (int k = 0; k < nd; ++k) {
+      const int cnt = std::min(c->H - 1, k) - std::max(0, k - (c->W - 1)) + 1;
+      start[k + 1] = start[k] + 2u * (unsigned)cnt;
+    }
+    if ((rc = dalloc(c, &c->d_sweep_start, start.size(), nullptr))) return rc;
+    HIPCHK(c, hipMemcpy(c->d_sweep_start, start.data(), start.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
+  }
   c->field_alloc = true;
   return CSPM_OK;
 }
@@ -343,6 +367,17 @@ Pm make_pm(cspm_ctx *c, const cspm_pm_params *p) {
   pm.f[0] = c->f[0];
   pm.f[1] = c->f[1];
   return pm;
+}
+
+// after a persistent sweep: its bounded spins raise ctrl[1] instead of hanging
+int check_sweep(cspm_ctx *c) {
+  if (!c->sweep_pending) return CSPM_OK;
+  unsigned int ctrl[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(ctrl, c->d_sweep_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sweep_pending = false;
+  if (ctrl[1]) return fail(c, CSPM_ERR_HIP, "raster sweep timed out waiting for a predecessor pixel (inter-workgroup hand-off)");
+  return CSPM_OK;
 }
 
 const cspm_pm_params kDefaultParams = {12345ULL, CSPM_SCHED_REDBLACK, 1, 4, CSPM_RNG_PER_PIXEL, 1};
@@ -386,6 +421,42 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
         Timed t(c, CSPM_K_SPATIAL, items * p->rb_neighbours);
         LAUNCH_CS(k_spatial_rb, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, (hs + iter) & 1, inc, p->rb_neighbours);
       }
+  } else if (!c->opt_raster_launches) {
+    // one persistent launch per sweep: 2 workgroups of 8 waves per CU pull pixels in diagonal-major order
+    Sweep sw{};
+    sw.ctrl = c->d_sweep_ctrl;
+    sw.done[0] = c->d_sweep_done;
+    sw.done[1] = c->d_sweep_done + (size_t)c->W * c->H;
+    sw.start = c->d_sweep_start;
+    sw.epoch = ++c->sweep_epoch;
+    sw.total = 2u * (unsigned)c->W * (unsigned)c->H;
+    sw.trace = nullptr;
+#ifdef CSPM_SWEEP_TRACE
+    {
+      static long long *d_trace = nullptr;
+      if (!d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * 8 * (size_t)sw.total);
+      sw.trace = d_trace;
+      if (const char *path = getenv("CSPM_SWEEP_TRACE_FILE")) {
+        static int sweep_no = 0;
+        if (sweep_no++ == 1) {  // dump the FIRST sweep's stamps when the second one is about to start
+          std::vector<long long> h((size_t)8 * sw.total);
+          (void)hipStreamSynchronize(c->stream);
+          (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+          if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), fp); fclose(fp); }
+        }
+      }
+    }
+#endif
+    HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * 6);  // more than fit is harmless: unclaimed work is all a late workgroup needs
+    const unsigned waves = c->cost.cs ? (unsigned)c->cost.levels : 4u;  // one wave per level, or per accumulator block
+    {
+      Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
+      LAUNCH_CS(k_spatial_sweep, dim3(grid), dim3(waves * kWave), 0, c->cost, pm, sw, inc);
+    }
+    c->sweep_pending = true;
   } else {
     for (int k = 1; k <= c->W + c->H - 2; ++k) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
@@ -543,6 +614,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
   if (!c) return CSPM_ERR_ARG;
   switch (key) {
     case CSPM_OPT_GRD_VOLUMES: c->opt_grd_volumes = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_RASTER_LAUNCHES: c->opt_raster_launches = value ? 1 : 0; return CSPM_OK;
     default: return fail(c, CSPM_ERR_ARG, "unknown option");
   }
 }
@@ -761,7 +833,9 @@ int cspm_pm_init(cspm_ctx *c, const cspm_pm_params *p) {
 }
 int cspm_pm_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   int rc = check_pm(c, &p);
-  return rc ? rc : do_spatial(c, iter, p);
+  if (rc) return rc;
+  if ((rc = do_spatial(c, iter, p))) return rc;
+  return check_sweep(c);
 }
 int cspm_pm_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   int rc = check_pm(c, &p);
@@ -780,6 +854,7 @@ int cspm_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
   if ((rc = do_init(c, p))) return rc;                 // cs_patchmatch.cc:55
   for (int i = 0; i < iter_num; ++i) {                 // :65-102
     if ((rc = do_spatial(c, i, p))) return rc;
+    if ((rc = check_sweep(c))) return rc;  // before the next sweep resets the control words
     if ((rc = do_view(c, i, p))) return rc;
     if ((rc = do_refine(c, i, p))) return rc;
   }

@@ -62,6 +62,15 @@ __device__ __forceinline__ u32x3 ld12(const PixG *base, int idx) {
 }
 __device__ __forceinline__ double g_of(const u32x3 &v) { return __hiloint2double((int)v.z, (int)v.y); }
 
+__device__ __forceinline__ void fill_tab(const Cost &cd, double *tab, int ox0, int oy0, double a, double b, double c, int lane) {
+  wave_lds_fence();  // earlier reads of this table are done
+  for (int l = lane; l < cd.n; l += kWave) {
+    tab[l] = a * (double)(ox0 + l);
+    tab[kTabSize + l] = b * (double)(oy0 + l) + c;
+  }
+  wave_lds_fence();
+}
+
 // Prepare one level for this wave: uniform arguments plus the two per-wave tables
 //   tab[dx]          = plane_a * q_x            (the product of pre_cs_pc.cc:165)
 //   tab[kTabSize+dy] = plane_b * q_y + plane_c  (q_disp_y, pre_cs_pc.cc:155)
@@ -82,12 +91,7 @@ __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut,
   A.vol = L.vol[view];
   A.slab = (size_t)L.W * (size_t)L.H;
   A.Ip = L.px[view][A.ocen].pix;
-  wave_lds_fence();  // the previous level's table reads are done
-  for (int l = lane; l < cd.n; l += kWave) {
-    lut.tab[l] = a * (double)(A.ox0 + l);
-    lut.tab[kTabSize + l] = b * (double)(A.oy0 + l) + c;
-  }
-  wave_lds_fence();
+  fill_tab(cd, lut.tab, A.ox0, A.oy0, a, b, c, lane);
   return A;
 }
 
@@ -107,25 +111,40 @@ __device__ __forceinline__ int cvt_i32_sat(double x) {
   return r;
 }
 
-// One window tap t (pre_cs_pc.cc:157-179): returns wgt * interpolated cell cost; taps outside the
-// window / image read the centre pixel with weight entry kLutZero (= 0.0) and so add +0.0.
+// One window tap t (pre_cs_pc.cc:157-179) in two parts, so that several candidate planes evaluated at the SAME
+// pixel share the plane-independent half (tap decode, bounds, own pixel, guide weight).
 // NB: every `c ? x : y` has plain locals on both sides.  clang emits a real branch for a conditional
 // operator with a member access in an arm, and LLVM then sinks all loads of the tap into that branch,
-// which serialises the four taps of a round behind s_waitcnt vmcnt(0).
-template <bool FUSED>
-__device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
-  const int ocen = A.ocen, lutzero = kLutZero, one = 1;
-  const double maxc = A.maxc;
+// which serialises the taps of a round behind s_waitcnt vmcnt(0).
+struct TapOwn {
+  int o, dx, dy;
+  bool ok;
+  u32x3 P;     // own pixel: colour, gradient
+  double wgt;  // lookup_exp_[|dB|+|dG|+|dR|] (:161-164); 0 for taps outside the window / image
+};
+
+__device__ __forceinline__ TapOwn tap_own(const LevelArgs &A, const Luts &lut, int t) {
+  const int ocen = A.ocen, lutzero = kLutZero;
+  TapOwn w;
   const int dec = (int)lut.dec[t];
-  const int dx = dec & 255, dy = (dec >> 8) & 255;
-  const bool ok = (dec >= 0) & ((unsigned)(A.oy0 + dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + dx) < (unsigned)A.W);
-  const int o0 = A.obase + __mul24(dy, A.Wp) + dx;  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
-  const int o = ok ? o0 : ocen;
-  const u32x3 P = ld12(A.px, o);
-  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, P.x, 0u);  // |dB|+|dG|+|dR|  (:161-163)
-  const int sum = ok ? sum0 : lutzero;
-  const double wgt = lut.w[sum];                                 // :164
-  const double q_disp = lut.tab[dx] + lut.tab[kTabSize + dy];    // :155,165 (masked taps: any finite or NaN value)
+  w.dx = dec & 255;
+  w.dy = (dec >> 8) & 255;
+  w.ok = (dec >= 0) & ((unsigned)(A.oy0 + w.dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + w.dx) < (unsigned)A.W);
+  const int o0 = A.obase + __mul24(w.dy, A.Wp) + w.dx;  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
+  w.o = w.ok ? o0 : ocen;                               // masked taps read the centre pixel ...
+  w.P = ld12(A.px, w.o);
+  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, w.P.x, 0u);
+  const int sum = w.ok ? sum0 : lutzero;                // ... with weight entry kLutZero = 0.0, so they add +0.0
+  w.wgt = lut.w[sum];
+  return w;
+}
+
+// plane-dependent half: tab = the candidate's tables (tab[dx] = a*qx, tab[kTabSize+dy] = b*qy+c)
+template <bool FUSED>
+__device__ __forceinline__ double tap_plane(const Cost &cd, const LevelArgs &A, const Luts &lut, const double *tab, const TapOwn &w) {
+  const int one = 1;
+  const double maxc = A.maxc;
+  const double q_disp = tab[w.dx] + tab[kTabSize + w.dy];        // :155,165 (masked taps: any finite or NaN value)
   // static_cast<int>(q_disp) in [1, D-1]  <=>  1.0 <= q_disp < D; NaN / out of int range -> the
   // "impossible disparity" branch (:166-169), as x86 cvttsd2si (INT_MIN) takes it.
   const bool valid = (q_disp >= 1.0) & (q_disp < A.Dd);
@@ -134,20 +153,26 @@ __device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, c
   const double floor_wgt = (double)(f + 1) - q_disp;             // :171-172
   double c0, c1;
   if (FUSED) {
-    const double Gq = g_of(P);
-    const int of = o + __mul24(A.dir, f);
-    c0 = grd_cell(lut, P.x, Gq, ld12(A.opx, of));
-    c1 = grd_cell(lut, P.x, Gq, ld12(A.opx, of + A.dir));
+    const double Gq = g_of(w.P);
+    const int of = w.o + __mul24(A.dir, f);
+    c0 = grd_cell(lut, w.P.x, Gq, ld12(A.opx, of));
+    c1 = grd_cell(lut, w.P.x, Gq, ld12(A.opx, of + A.dir));
   } else {
     const int hh = cd.half;
-    const int dyc = ok ? dy : hh, dxc = ok ? dx : hh;
+    const int dyc = w.ok ? w.dy : hh, dxc = w.ok ? w.dx : hh;
     const double *p = A.vol + (size_t)f * A.slab + (size_t)(A.oy0 + dyc) * A.W + (A.ox0 + dxc);
     c0 = p[0];
     c1 = p[A.slab];
   }
   double tmp = floor_wgt * c0 + (1 - floor_wgt) * c1;            // :173-175
   tmp = valid ? tmp : maxc;                                      // :169
-  return wgt * tmp;                                              // :176
+  return w.wgt * tmp;                                            // :176
+}
+
+template <bool FUSED>
+__device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
+  const TapOwn w = tap_own(A, lut, t);
+  return tap_plane<FUSED>(cd, A, lut, lut.tab, w);
 }
 
 // Cheap wave-wide LOWER-BOUND sum for the early-exit test: f32 DPP reduction (6 VALU instructions, no
@@ -228,20 +253,20 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
   return cost;
 }
 
-template <int WAVES>
+template <int WAVES, int TABS = 1>
 struct LutMem {
   double w[kLutSize];
   double a[kLutSize];
-  double tab[WAVES][2 * kTabSize];
+  double tab[WAVES][TABS * 2 * kTabSize];
   uint32_t dec[kMaxRounds * 256];
 };
-template <int WAVES>
-__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem<WAVES> &m) {
+template <int WAVES, int TABS>
+__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem<WAVES, TABS> &m) {
   for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) {
     m.w[i] = i == kLutZero ? 0.0 : cd.lut[i];
     m.a[i] = cd.lut_a[i];
   }
-  for (int i = threadIdx.x; i < WAVES * 2 * kTabSize; i += blockDim.x) (&m.tab[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < WAVES * TABS * 2 * kTabSize; i += blockDim.x) (&m.tab[0][0])[i] = 0.0;
   for (int i = threadIdx.x; i < cd.rounds * 256; i += blockDim.x) m.dec[i] = cd.dec[i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -467,6 +492,209 @@ __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int
       const long long q = pick == 0 ? i - inc : i - (long long)inc * pm.W;
       store_plane(f, i, f.nx[q], f.ny[q], f.nz[q], f.a[q], f.b[q], f.c[q], best_cost);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same raster sweep as ONE persistent launch (default): workgroups pull pixels in diagonal-major
+// order from a device-wide counter and wait, per pixel, for the "done" flags of its two predecessors
+// instead of for a kernel boundary.  Dataflow instead of 1615 launches per sweep: a pixel starts as
+// soon as ITS predecessors are final, diagonals overlap, and the ~15 us fixed cost per launch is gone.
+//
+// Inter-workgroup protocol (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1 never
+// refreshed by other CUs' stores): every word another workgroup may read -- the 7 doubles of a plane
+// and the done flag -- is written with 8-byte / 4-byte AGENT-scope atomic stores (write-through) and
+// read with agent-scope atomic loads (L1 bypass), both sides; the producer drains its stores
+// (s_waitcnt vmcnt(0)) before it stores the flag.  No fences, no reliance on placement or dispatch
+// order.  Deadlock freedom: pixels are claimed in an order in which predecessors come first, so every
+// flag a workgroup waits for belongs to a pixel already claimed by a running workgroup.  Every spin is
+// bounded (wall clock); a timeout raises ctrl[1] and all workgroups drain.
+// ------------------------------------------------------------------------------------------------
+struct Sweep {
+  unsigned int *ctrl;         // [0] next item, [1] error
+  unsigned int *done[2];      // per view, per pixel: epoch of the last sweep that finalised the pixel
+  const unsigned int *start;  // start[k] = items (both views) on diagonals < k; W+H entries
+  unsigned int epoch, total;
+  long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
+};
+#ifdef CSPM_SWEEP_TRACE
+#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[(size_t)item * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SWEEP_STAMP(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int epoch, unsigned int *err) {
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 255u) == 0u) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (wall_clock64() - t0 > 300000000LL) {  // 3 s of the 100 MHz constant clock
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+// Both candidates of a sweep pixel (the planes of its x- and y-predecessor) are evaluated at the same pixel,
+// i.e. over the same window: one pass computes the plane-independent half of every tap once and the
+// plane-dependent half twice.  NC = number of candidates present (2 except on the first sweep row / column).
+// Returns exact SLOT256 sums, identical in all lanes.
+template <bool FUSED, int NC>
+__device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs &A, const Luts &lut, int t_first, int t_step,
+                                                int t_end, const double *tab0, const double *tab1, double acc0[4], double acc1[4]) {
+  for (int t = t_first; t < t_end; t += t_step) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const TapOwn w = tap_own(A, lut, t + 64 * u);
+      acc0[u] += tap_plane<FUSED>(cd, A, lut, tab0, w);
+      if (NC == 2) acc1[u] += tap_plane<FUSED>(cd, A, lut, tab1, w);
+    }
+  }
+}
+
+// Work split inside a sweep workgroup: cross-scale -> one wave per pyramid level (`levels` waves); single-scale
+// -> 4 waves, one per SLOT256 accumulator block.  Every wave handles both candidates.
+constexpr int kSweepMaxWaves = 8;
+
+template <bool CS, bool FUSED>
+__global__ __launch_bounds__(kSweepMaxWaves * kWave, 4) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
+  __shared__ LutMem<kSweepMaxWaves, 2> s_lut;
+  __shared__ double s_part[2][4][kWave];        // single-scale: per-lane partials of the 4 accumulator blocks
+  __shared__ double s_lvl[2][CSPM_MAX_LEVELS];  // cross-scale: exact level sums
+  __shared__ double s_plane[2][6];
+  __shared__ unsigned int s_item;
+  __shared__ int s_ok;
+  const Luts lut = load_luts(cd, s_lut);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const double *tab0 = lut.tab, *tab1 = lut.tab + 2 * kTabSize;
+  const int ndiag = pm.W + pm.H - 1;
+  int k = 0;
+  unsigned int next_item = 0;
+  if (threadIdx.x == 0) next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    if (threadIdx.x == 0) {
+      s_item = next_item;
+      s_ok = 1;
+      // claim the following item now: the atomic's latency hides behind this item's work.  Claims of a
+      // workgroup stay increasing, which is all the deadlock argument needs.
+      if (next_item < sw.total) next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned int item = s_item;
+    if (item >= sw.total) return;
+    SWEEP_STAMP(0);
+    while (k + 1 < ndiag && item >= sw.start[k + 1]) ++k;  // items of one workgroup only increase
+    const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
+    const int cnt = ys_hi - ys_lo + 1;
+    const int r = (int)(item - sw.start[k]);
+    const int v = r / cnt;
+    const int ys = ys_lo + (r - v * cnt), xs = k - ys;
+    const int x = inc > 0 ? xs : pm.W - 1 - xs, y = inc > 0 ? ys : pm.H - 1 - ys;
+    const Field &f = pm.f[v];
+    const long long i = (long long)y * pm.W + x;
+    const long long jx = i - inc, jy = i - (long long)inc * pm.W;
+    const bool have0 = xs > 0, have1 = ys > 0;
+    SWEEP_STAMP(1);
+    // 1. wait for the predecessors: lanes 0 and 1 of wave 0 poll one flag each
+    if (wave == 0 && lane < 2) {
+      const bool need = lane == 0 ? have0 : have1;
+      if (need && !wait_done(sw.done[v] + (lane == 0 ? jx : jy), sw.epoch, &sw.ctrl[1])) s_ok = 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    asm volatile("" ::: "memory");
+    SWEEP_STAMP(2);
+    // 2. both candidate costs in one pass over the window
+    if (have0 || have1) {
+      // with one candidate missing, both slots hold the existing one (the duplicate is computed once, NC = 1)
+      const long long j0 = have0 ? jx : jy, j1 = have1 ? jy : jx;
+      const Cand c0{ld_agent(f.nx + j0), ld_agent(f.ny + j0), ld_agent(f.nz + j0), ld_agent(f.a + j0), ld_agent(f.b + j0), ld_agent(f.c + j0)};
+      const Cand c1{ld_agent(f.nx + j1), ld_agent(f.ny + j1), ld_agent(f.nz + j1), ld_agent(f.a + j1), ld_agent(f.b + j1), ld_agent(f.c + j1)};
+      if (wave == 0 && lane == 0) {
+        s_plane[0][0] = c0.nx; s_plane[0][1] = c0.ny; s_plane[0][2] = c0.nz; s_plane[0][3] = c0.a; s_plane[0][4] = c0.b; s_plane[0][5] = c0.c;
+        s_plane[1][0] = c1.nx; s_plane[1][1] = c1.ny; s_plane[1][2] = c1.nz; s_plane[1][3] = c1.a; s_plane[1][4] = c1.b; s_plane[1][5] = c1.c;
+      }
+      const bool both = have0 && have1;
+      SWEEP_STAMP(3);
+      double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+      if (CS) {
+        // this wave's level `wave`: (cur_x, cur_y, cur_disp) after `wave` halvings (pre_cs_pc.cc:139-140,183-185)
+        double d0 = c0.a * (double)x + c0.b * (double)y + c0.c, d1 = c1.a * (double)x + c1.b * (double)y + c1.c;
+        int cur_x = x, cur_y = y;
+        for (int s = 0; s < wave; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
+        double pa, pb, pc;
+        plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pa, pb, pc);  // :144-149
+        const LevelArgs A = make_level(cd, lut, wave, v, cur_x, cur_y, pa, pb, pc, lane);
+        if (both) {
+          plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
+          fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, pa, pb, pc, lane);
+          level_cost_pair<FUSED, 2>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
+        } else {
+          level_cost_pair<FUSED, 1>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
+        }
+        const double s0 = wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
+        const double s1 = both ? wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3])) : s0;
+        if (lane == 0) { s_lvl[0][wave] = s0; s_lvl[1][wave] = s1; }
+      } else {
+        // single scale: wave = accumulator block; tap t = q*256 + wave*64 + lane, one accumulator per lane
+        const LevelArgs A = make_level(cd, lut, 0, v, x, y, c0.a, c0.b, c0.c, lane);
+        if (both) fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, c1.a, c1.b, c1.c, lane);
+        double p0 = 0.0, p1 = 0.0;
+        for (int q = 0; q < cd.rounds; ++q) {
+          const TapOwn w = tap_own(A, lut, q * 256 + wave * 64 + lane);
+          p0 += tap_plane<FUSED>(cd, A, lut, tab0, w);
+          if (both) p1 += tap_plane<FUSED>(cd, A, lut, tab1, w);
+        }
+        s_part[0][wave][lane] = p0;
+        s_part[1][wave][lane] = both ? p1 : p0;
+      }
+    }
+    SWEEP_STAMP(4);
+    __syncthreads();
+    SWEEP_STAMP(5);
+    // 3. accept (x-predecessor first, then y-predecessor against the updated minimum), publish, raise the flag
+    if (wave == 0) {
+      double cost0 = 0.0, cost1 = 0.0;
+      if (have0 || have1) {
+        if (CS) {
+          for (int s = 0; s < cd.levels; ++s) {  // :182, levels in order
+            cost0 += s_lvl[0][s] * cd.lv[s].wgt;
+            cost1 += s_lvl[1][s] * cd.lv[s].wgt;
+          }
+        } else {
+          cost0 = wave_sum((s_part[0][0][lane] + s_part[0][1][lane]) + (s_part[0][2][lane] + s_part[0][3][lane]));
+          cost1 = wave_sum((s_part[1][0][lane] + s_part[1][1][lane]) + (s_part[1][2][lane] + s_part[1][3][lane]));
+        }
+      }
+      if (lane == 0) {
+        double best_cost = f.cost[i];  // own pixel: nobody else writes it during the sweep
+        int pick = -1;
+        if (have0 && cost0 < best_cost) { best_cost = cost0; pick = 0; }
+        if (have1 && cost1 < best_cost) { best_cost = cost1; pick = 1; }
+        if (pick >= 0) {
+          st_agent(f.nx + i, s_plane[pick][0]); st_agent(f.ny + i, s_plane[pick][1]); st_agent(f.nz + i, s_plane[pick][2]);
+          st_agent(f.a + i, s_plane[pick][3]); st_agent(f.b + i, s_plane[pick][4]); st_agent(f.c + i, s_plane[pick][5]);
+          st_agent(f.cost + i, best_cost);
+        }
+        SWEEP_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the plane is in memory before the flag can be seen
+        __hip_atomic_store(sw.done[v] + i, sw.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SWEEP_STAMP(7);
+      }
+    }
+    __syncthreads();  // s_item / s_plane / s_lvl are reused by the next item
   }
 }
 

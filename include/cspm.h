@@ -77,6 +77,10 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * volume in HBM); 1 = materialise the d-major f64 volumes exactly as PreCSPC does (pre_cs_pc.cc:50-73)
  * and read them. */
 #define CSPM_OPT_GRD_VOLUMES 1
+/* CSPM_OPT_RASTER_LAUNCHES: 0 (default) = the reference-order raster sweep runs as ONE persistent launch whose
+ * workgroups hand pixels over through per-pixel done flags; 1 = one launch per anti-diagonal (W+H-2 launches
+ * per sweep; same results, kept as a cross-check). */
+#define CSPM_OPT_RASTER_LAUNCHES 2
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
  * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */

@@ -142,3 +142,20 @@ def test_golden_pipeline_fixture(gpu_ctx):
                 assert cost.sum() == g[k + "_cost_sum"][v]
             l, r = gpu_ctx.postprocess(int(g["dis_scale"]))
             np.testing.assert_array_equal(np.stack([l, r]), g[k + "_pp"])
+
+
+@pytest.mark.parametrize("pairname", ["odd_pair", "mid_pair"])
+def test_raster_sweep_persistent_equals_per_diagonal_launches(gpu_ctx, request, pairname):
+    """The persistent dataflow sweep (per-pixel done flags across workgroups / XCDs) and the one-launch-per-
+    anti-diagonal sweep are the same computation; both equal the oracle's serial raster loop."""
+    from crossscalepatchmatch_amd import capi
+    pair = request.getfixturevalue(pairname)
+    pc, pm = _setup(gpu_ctx, pair, 5, 0.3)
+    pm.run(3, pc, False, seed=606, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    try:
+        for launches in (1, 0, 0):  # the persistent variant twice: epochs advance, flags are reused
+            gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, launches)
+            gpu_ctx.patchmatch(3, seed=606, schedule=po.SCHED_RASTER)
+            _assert_state_equal(gpu_ctx, pm, f"raster launches={launches}")
+    finally:
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
