@@ -655,6 +655,74 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   return finish_cost(c);
 }
 
+// `new PreSSPC/PreCSPC(l, r, max_dis, wnd, [scale_num,] new CenCC, [reg_lambda])`: census volumes of every level
+// built on the device (cc/cen_cc.cc:4-137), then read by the PatchMatch kernels like any CCMethod's volumes.
+int cspm_build_cost_cen(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+  if (!c) return CSPM_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, true);
+  if (rc) return rc;
+  Cost &cd = c->cost;
+  std::vector<void *> tmp;
+  auto done = [&](int code) {
+    for (void *p : tmp) (void)hipFree(p);
+    return code;
+  };
+  for (int s = 0; s < cd.levels; ++s) {
+    const Level &L = cd.lv[s];
+    const long long px = (long long)L.W * L.H, ppx = (long long)L.Wp * L.H;
+    uint8_t *gray[2];
+    uint32_t *code[2];
+    for (int v = 0; v < 2; ++v) {
+      if ((rc = dalloc(c, &gray[v], (size_t)px, &tmp)) || (rc = dalloc(c, &code[v], (size_t)px * 3, &tmp))) return done(rc);
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_gray8<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H, gray[v]);
+      hipLaunchKernelGGL(k_census, dim3(ew_grid(px)), dim3(256), 0, c->stream, gray[v], L.W, L.H, code[v]);
+      hipLaunchKernelGGL(k_make_aos, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)nullptr, ppx, (PixG *)L.px[v]);
+    }
+    for (int v = 0; v < 2; ++v) {
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid(px * (L.D + 1))), dim3(256), 0, c->stream, code[0], code[1], L.W, L.H, L.D + 1, v,
+                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return done(finish_cost(c));
+}
+
+// CenCC::buildCV / buildRightCV on host buffers (cc_method.h:31-32, cc/cen_cc.cc:4-137)
+int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, int right_view, double *vol_out) {
+  if (!l_rgb || !r_rgb || !vol_out || w < 1 || h < 1 || maxDis < 1) return fail(nullptr, CSPM_ERR_ARG, "bad arguments");
+  cspm_ctx *c = nullptr;
+  int rc = cspm_create(&c, device);
+  if (rc) return rc;
+  const size_t px = (size_t)w * h;
+  double *d[2] = {nullptr, nullptr}, *vol = nullptr;
+  uint8_t *gray[2];
+  uint32_t *code[2];
+  std::vector<void *> tmp;
+  auto done = [&](int code_) {
+    if (code_) g_create_error = c->err;
+    for (void *p : tmp) (void)hipFree(p);
+    cspm_destroy(c);
+    return code_;
+  };
+  const double *src[2] = {l_rgb, r_rgb};
+  for (int v = 0; v < 2; ++v) {
+    if ((rc = dalloc(c, &d[v], px * 3, &tmp)) || (rc = dalloc(c, &gray[v], px, &tmp)) || (rc = dalloc(c, &code[v], px * 3, &tmp))) return done(rc);
+    if (hipMemcpyAsync(d[v], src[v], sizeof(double) * px * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess) return done(fail(c, CSPM_ERR_HIP, "upload failed"));
+    hipLaunchKernelGGL(k_gray8<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{d[v], w}, w, h, gray[v]);
+    hipLaunchKernelGGL(k_census, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, gray[v], w, h, code[v]);
+  }
+  if ((rc = dalloc(c, &vol, px * maxDis, &tmp))) return done(rc);
+  hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, code[0], code[1], w, h, maxDis, right_view, vol,
+                     (unsigned long long *)nullptr);
+  if (hipMemcpyAsync(vol_out, vol, sizeof(double) * px * maxDis, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+    return done(fail(c, CSPM_ERR_HIP, "census volume kernel failed"));
+  return done(CSPM_OK);
+}
+
 int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));

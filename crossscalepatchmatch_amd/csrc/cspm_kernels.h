@@ -1062,6 +1062,75 @@ __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *
   if (max_key && (threadIdx.x & 63) == 0) atomicMax(max_key, key);
 }
 
+// ------------------------------------------------------------------------------------------------
+// CenCC (cc/cen_cc.cc:4-137): 8-bit gray, 9x9 census code (80 bits, wrap-around border), Hamming volume.
+// ------------------------------------------------------------------------------------------------
+// cen_cc.cc:13-16: convertTo(CV_8U) = saturate(round half even), cvtColor(CV_RGB2GRAY) on 8U =
+// (R*4899 + G*9617 + B*1868 + (1<<13)) >> 14  (OpenCV 2.4 fixed point)
+template <class Src>
+__global__ void k_gray8(Src s, int W, int H, uint8_t *__restrict__ gray) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)W * H) return;
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  double r, g, b;
+  s.rgb(x, y, r, g, b);
+  const double v[3] = {r, g, b};
+  int c[3];
+  for (int k = 0; k < 3; ++k) {
+    const int q = v[k] >= 2147483647.0 ? 2147483647 : (v[k] <= -2147483648.0 ? -2147483647 - 1 : __double2int_rn(v[k]));
+    c[k] = q < 0 ? 0 : (q > 255 ? 255 : q);
+  }
+  gray[i] = (uint8_t)((c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + (1 << 13)) >> 14);
+}
+__device__ __forceinline__ int wrap_mod(int v, int n) {  // (v + n) % n of cen_cc.cc:30,34, kept non-negative for n < 4
+  const int r = v % n;
+  return r < 0 ? r + n : r;
+}
+// cen_cc.cc:19-45: bit k = centre > k-th neighbour of the 9x9 window (row-major, centre skipped), LSB first
+__global__ void k_census(const uint8_t *__restrict__ gray, int W, int H, uint32_t *__restrict__ code) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)W * H) return;
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  const int c = gray[i];
+  uint32_t w[3] = {0u, 0u, 0u};
+  int bit = 0;
+  for (int wy = -4; wy <= 4; ++wy) {
+    const uint8_t *row = gray + (size_t)wrap_mod(y + wy, H) * W;
+    for (int wx = -4; wx <= 4; ++wx) {
+      if (wy == 0 && wx == 0) continue;
+      if (c > row[wrap_mod(x + wx, W)]) w[bit >> 5] |= 1u << (bit & 31);
+      ++bit;
+    }
+  }
+  code[3 * i] = w[0]; code[3 * i + 1] = w[1]; code[3 * i + 2] = w[2];
+}
+// cen_cc.cc:47-66 / 114-133: Hamming distance of the two codes, CENCUS_BIT = 80 where the other view is outside
+__global__ __launch_bounds__(256) void k_cen_volume(const uint32_t *__restrict__ lc, const uint32_t *__restrict__ rc, int W, int H, int nd,
+                                                    int right_view, double *__restrict__ vol, unsigned long long *max_key) {
+  const long long slab = (long long)W * H, cells = slab * nd;
+  double best = -1.7976931348623157e308;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i / slab);
+    const long long o = i - (long long)d * slab;
+    const int y = (int)(o / W), x = (int)(o - (long long)y * W);
+    const int xo = right_view ? x + d : x - d;
+    double cost = 80.0;
+    if (right_view ? (xo < W) : (xo >= 0)) {
+      const uint32_t *a = (right_view ? rc : lc) + 3 * o, *b = (right_view ? lc : rc) + 3 * ((long long)y * W + xo);
+      cost = (double)(__popc(a[0] ^ b[0]) + __popc(a[1] ^ b[1]) + __popc(a[2] ^ b[2]));
+    }
+    vol[i] = cost;
+    best = cost > best ? cost : best;
+  }
+  unsigned long long key = f64_key(best);
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const unsigned long long other = __shfl_xor(key, off, kWave);
+    key = other > key ? other : key;
+  }
+  if (max_key && (threadIdx.x & 63) == 0) atomicMax(max_key, key);
+}
+
 // max over an uploaded (foreign CCMethod) volume
 __global__ __launch_bounds__(256) void k_volume_max(const double *__restrict__ vol, long long cells, unsigned long long *max_key) {
   unsigned long long key = f64_key(-1.7976931348623157e308);

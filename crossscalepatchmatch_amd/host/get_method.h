@@ -2,12 +2,14 @@
 // main.cc:39-55): unknown or unimplemented names yield NULL.
 #pragma once
 #include "ca_method.h"
+#include "cc/cen_cc.h"
 #include "cc/grd_cc.h"
 #include "cc_method.h"
 
 inline CCMethod *getCCType(const string &name) {
   if (name == "GRD") return new GrdCC();
-  return NULL;  // "CEN", "BSM", "CG": no implementation in this build
+  if (name == "CEN") return new CenCC();
+  return NULL;  // "BSM", "CG": NULL in the reference too (main.cc:47-54)
 }
 inline CCMethod *GetCCType(const string &name) { return getCCType(name); }  // spelling used by main.cc:39
 inline CAMethod *getCAType(const string &) { return NULL; }                 // "GF", "BF", "BOX", "NL", "ST"

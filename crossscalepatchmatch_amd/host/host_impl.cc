@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "../../include/cspm.h"
+#include "cc/cen_cc.h"
 #include "cc/grd_cc.h"
 #include "cs_patchmatch.h"
 #include "plane_cost/device_plane_cost.h"
@@ -36,6 +37,21 @@ void GrdCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int ri
 void GrdCC::buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol) { build(lImg, rImg, maxDis, costVol, 0); }
 void GrdCC::buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol) { build(lImg, rImg, maxDis, rCostVol, 1); }
 
+// ---------------------------------------------------------------- CenCC (cc/cen_cc.cc:4-137)
+void CenCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int right) {
+  CV_Assert(lImg.type() == CV_64FC3 && rImg.type() == CV_64FC3);  // cen_cc.cc:7
+  CV_Assert(lImg.rows == rImg.rows && lImg.cols == rImg.cols && maxDis >= 1 && vol);
+  const int h = lImg.rows, w = lImg.cols;
+  std::vector<double> l = packed64(lImg), r = packed64(rImg), out((size_t)maxDis * h * w);
+  check(cspm_cen_build_cv_host(device_, l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "CenCC");
+  for (int d = 0; d < maxDis; ++d) {
+    if (vol[d].rows != h || vol[d].cols != w || vol[d].type() != CV_64FC1) vol[d].create(h, w, CV_64FC1);
+    for (int y = 0; y < h; ++y) std::memcpy(vol[d].ptr<double>(y), &out[((size_t)d * h + y) * w], sizeof(double) * w);
+  }
+}
+void CenCC::buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol) { build(lImg, rImg, maxDis, costVol, 0); }
+void CenCC::buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol) { build(lImg, rImg, maxDis, rCostVol, 1); }
+
 // ---------------------------------------------------------------- PreSSPC / PreCSPC
 int DevicePlaneCost::device = 0;
 
@@ -51,6 +67,10 @@ DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_dis
   if (dynamic_cast<GrdCC *>(cc_method)) {
     // the known cost function: pyramid, gradients, max_cost, scale weights all on the device
     check(cspm_build_cost_grd(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_grd");
+    return;
+  }
+  if (dynamic_cast<CenCC *>(cc_method)) {
+    check(cspm_build_cost_cen(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_cen");
     return;
   }
   // a foreign CCMethod: let it fill host volumes level by level exactly as pre_cs_pc.cc:57-74 does

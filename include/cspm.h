@@ -82,6 +82,9 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * per sweep; same results, kept as a cross-check). */
 #define CSPM_OPT_RASTER_LAUNCHES 2
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
+/* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census / Hamming cost volumes of
+ * every level built on the device and kept in HBM (f64, d-major, as the reference stores them). */
+int cspm_build_cost_cen(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
 /* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
  * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */
 int cspm_begin_cost(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
@@ -98,6 +101,10 @@ int cspm_get_scale_weights(const cspm_ctx *ctx, double *out /* levels */);
 /* CCMethod::buildCV / buildRightCV on host buffers (cc_method.h:31-32, cc/grd_cc.cpp:60-154):
  * l_rgb/r_rgb are h*w*3 doubles (CV_64FC3, RGB, 0..255), vol_out receives maxDis slabs of h*w. */
 int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis,
+                           int right_view, double *vol_out);
+
+/* CenCC::buildCV / buildRightCV on host buffers (cc/cen_cc.cc:4-70, 72-137), same contract as above */
+int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis,
                            int right_view, double *vol_out);
 
 /* ---- IPlaneCost::GetPlaneCost, batched (plane_cost/i_plane_cost.h:28-33) ----------------------

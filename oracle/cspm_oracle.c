@@ -279,6 +279,74 @@ void csor_grd_build_right_cv(const double *l, const double *r, int w, int h, int
   free(rG);
 }
 
+/* ------------------------------------------------------------------ census cost computation */
+
+/* cen_cc.cc:13-16: convertTo(CV_8U) (saturate_cast<uchar>(cvRound(v))) then cvtColor(CV_RGB2GRAY) on 8U =
+ * OpenCV 2.4 fixed point: (R*4899 + G*9617 + B*1868 + (1<<13)) >> 14. */
+static void rgb64_to_gray8(const double *rgb, int w, int h, uint8_t *gray) {
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    int c[3];
+    for (int k = 0; k < 3; ++k) {
+      double v = rgb[i * 3 + k];
+      int q = (int)nearbyint(v); /* cvRound: round half to even */
+      c[k] = q < 0 ? 0 : (q > 255 ? 255 : q);
+    }
+    gray[i] = (uint8_t)((c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + (1 << 13)) >> 14);
+  }
+}
+
+static inline int wrap(int v, int n) { /* (v + n) % n of cen_cc.cc:30,34; made non-negative for n < 4 (UB in the reference) */
+  int r = v % n;
+  return r < 0 ? r + n : r;
+}
+
+/* cen_cc.cc:19-45: 9x9 census, 80 bits, bit k = (centre > neighbour), wrap-around borders; bits packed LSB first */
+static void census_codes(const uint8_t *gray, int w, int h, uint32_t *code /* 3 words per pixel */) {
+  const int H_WD = 9 / 2;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      uint32_t *c = code + ((size_t)y * w + x) * 3;
+      c[0] = c[1] = c[2] = 0;
+      int bitCnt = 0;
+      for (int wy = -H_WD; wy <= H_WD; wy++) {
+        int qy = wrap(y + wy, h);
+        for (int wx = -H_WD; wx <= H_WD; wx++)
+          if (wy != 0 || wx != 0) {
+            int qx = wrap(x + wx, w);
+            if (gray[(size_t)y * w + x] > gray[(size_t)qy * w + qx]) c[bitCnt >> 5] |= 1u << (bitCnt & 31);
+            bitCnt++;
+          }
+      }
+    }
+}
+static inline int hamming80(const uint32_t *a, const uint32_t *b) {
+  return __builtin_popcount(a[0] ^ b[0]) + __builtin_popcount(a[1] ^ b[1]) + __builtin_popcount(a[2] ^ b[2]);
+}
+
+static void cen_build(const double *l, const double *r, int w, int h, int maxDis, int right, double *vol) {
+  uint8_t *lg = (uint8_t *)malloc((size_t)w * h), *rg = (uint8_t *)malloc((size_t)w * h);
+  uint32_t *lc = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (size_t)w * h), *rc = (uint32_t *)malloc(sizeof(uint32_t) * 3 * (size_t)w * h);
+  rgb64_to_gray8(l, w, h, lg);
+  rgb64_to_gray8(r, w, h, rg);
+  census_codes(lg, w, h, lc);
+  census_codes(rg, w, h, rc);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++)
+      for (int d = 0; d < maxDis; d++) {
+        double *cost = vol + ((size_t)d * h + y) * w;
+        cost[x] = 80; /* CENCUS_BIT, cen_cc.cc:56,123 */
+        if (!right) { /* cen_cc.cc:47-66 */
+          if (x - d >= 0) cost[x] = hamming80(lc + ((size_t)y * w + x) * 3, rc + ((size_t)y * w + x - d) * 3);
+        } else {      /* cen_cc.cc:114-133 */
+          if (x + d < w) cost[x] = hamming80(rc + ((size_t)y * w + x) * 3, lc + ((size_t)y * w + x + d) * 3);
+        }
+      }
+  free(lg); free(rg); free(lc); free(rc);
+}
+/* CenCC::buildCV / buildRightCV (cc/cen_cc.cc:4-70, 72-137) */
+void csor_cen_build_cv(const double *l, const double *r, int w, int h, int maxDis, double *vol) { cen_build(l, r, w, h, maxDis, 0, vol); }
+void csor_cen_build_right_cv(const double *l, const double *r, int w, int h, int maxDis, double *vol) { cen_build(l, r, w, h, maxDis, 1, vol); }
+
 /* ------------------------------------------------------------------ PreSSPC / PreCSPC */
 
 #define CSOR_MAX_LEVELS 16
@@ -318,6 +386,11 @@ void csor_pc_refresh_max_cost(csor_pc *pc) { /* pre_cs_pc.cc:75-82, pre_ss_pc.cc
 
 csor_pc *csor_pc_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h, int max_disp,
                         int wnd_size, int scale_num, double reg_lambda) {
+  return csor_pc_create_cc(l_bgr, r_bgr, w, h, max_disp, wnd_size, scale_num, reg_lambda, CSOR_CC_GRD);
+}
+
+csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h, int max_disp,
+                           int wnd_size, int scale_num, double reg_lambda, int cc_kind) {
   if (scale_num < 0 || scale_num > CSOR_MAX_LEVELS || w < 1 || h < 1 || max_disp < 1) return NULL;
   csor_pc *pc = (csor_pc *)calloc(1, sizeof *pc);
   pc->cs = scale_num > 0;
@@ -347,8 +420,13 @@ csor_pc *csor_pc_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h
     const size_t n = (size_t)(pc->max_disp[s] + 1) * pc->hei[s] * pc->wid[s];
     pc->vol[0][s] = (double *)calloc(n, sizeof(double));
     pc->vol[1][s] = (double *)calloc(n, sizeof(double));
-    csor_grd_build_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[0][s]);
-    csor_grd_build_right_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[1][s]);
+    if (cc_kind == CSOR_CC_CEN) {
+      csor_cen_build_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[0][s]);
+      csor_cen_build_right_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[1][s]);
+    } else {
+      csor_grd_build_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[0][s]);
+      csor_grd_build_right_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[1][s]);
+    }
     free(tl);
     free(tr);
   }

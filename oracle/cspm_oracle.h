@@ -69,6 +69,12 @@ void   csor_grd_build_right_cv(const double *l_rgb, const double *r_rgb, int w, 
 void   csor_rgb2gray_f32(const double *rgb, int w, int h, float *gray);
 void   csor_sobel_x_ks1(const float *gray, int w, int h, double *grd);
 
+/* CenCC::buildCV / buildRightCV (cc/cen_cc.cc:4-137): 9x9 census (80 bits, wrap-around border, gray via the 8U
+ * RGB2GRAY fixed-point contract), Hamming distance, 80 where the other view is outside the image */
+void   csor_cen_build_cv(const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, double *vol);
+void   csor_cen_build_right_cv(const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, double *vol);
+enum { CSOR_CC_GRD = 0, CSOR_CC_CEN = 1 };  /* main.cc:39-55 GetCCType("GRD" / "CEN") */
+
 /* ---------------- plane cost objects: PreSSPC / PreCSPC ---------------- */
 typedef struct csor_pc csor_pc;
 /* scale_num == 0  -> PreSSPC (pre_ss_pc.cc:12-65), single level, GetPlaneCost uses plane.param()
@@ -76,6 +82,8 @@ typedef struct csor_pc csor_pc;
  * l_bgr/r_bgr: packed 8UC3 BGR, h rows of w*3 bytes.  cost function: GRD. */
 csor_pc *csor_pc_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h,
                         int max_disp, int wnd_size, int scale_num, double reg_lambda);
+csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h,
+                           int max_disp, int wnd_size, int scale_num, double reg_lambda, int cc_kind);
 void     csor_pc_destroy(csor_pc *pc);
 int      csor_pc_levels(const csor_pc *pc);
 void     csor_pc_level_dims(const csor_pc *pc, int s, int *w, int *h, int *max_disp);

@@ -56,6 +56,9 @@ def lib():
         "csor_rgb2gray_f32": (None, [dp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
         "csor_sobel_x_ks1": (None, [C.POINTER(C.c_float), C.c_int, C.c_int, dp]),
         "csor_pc_create": (C.c_void_p, [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
+        "csor_pc_create_cc": (C.c_void_p, [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+        "csor_cen_build_cv": (None, [dp, dp, C.c_int, C.c_int, C.c_int, dp]),
+        "csor_cen_build_right_cv": (None, [dp, dp, C.c_int, C.c_int, C.c_int, dp]),
         "csor_pc_destroy": (None, [C.c_void_p]),
         "csor_pc_levels": (C.c_int, [C.c_void_p]),
         "csor_pc_level_dims": (None, [C.c_void_p, C.c_int, ip, ip, ip]),
@@ -108,12 +111,12 @@ def _bgr(img):
 class PlaneCost:
     """PreSSPC (scale_num=0) / PreCSPC (scale_num>=1) with the GRD cost."""
 
-    def __init__(self, l_bgr, r_bgr, max_disp, wnd_size=35, scale_num=0, reg_lambda=0.0):
+    def __init__(self, l_bgr, r_bgr, max_disp, wnd_size=35, scale_num=0, reg_lambda=0.0, cc="GRD"):
         self.L = lib()
         self.l, self.r = _bgr(l_bgr), _bgr(r_bgr)
         self.h, self.w = self.l.shape[:2]
-        self.p = self.L.csor_pc_create(_u8(self.l), _u8(self.r), self.w, self.h, max_disp, wnd_size, scale_num,
-                                       reg_lambda)
+        self.p = self.L.csor_pc_create_cc(_u8(self.l), _u8(self.r), self.w, self.h, max_disp, wnd_size, scale_num,
+                                          reg_lambda, {"GRD": 0, "CEN": 1}[cc])
         if not self.p:
             raise ValueError("csor_pc_create failed")
         self.levels = self.L.csor_pc_levels(self.p)

@@ -81,6 +81,35 @@ def grd_volume(l_bgr, r_bgr, max_dis_slabs, right):  # grd_cc.cpp:60-154 + myCos
     return vol
 
 
+def cen_volume(l_bgr, r_bgr, max_dis_slabs, right):  # cen_cc.cc:4-137
+    def gray8(bgr):  # convertTo(CV_8U) of u8-valued doubles, cvtColor(CV_RGB2GRAY) 8U fixed point
+        b, g, r = (bgr[..., k].astype(np.int64) for k in range(3))
+        return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.int64)
+
+    def codes(gray):
+        h, w = gray.shape
+        out = np.zeros((h, w, 80), bool)
+        k = 0
+        for wy in range(-4, 5):
+            for wx in range(-4, 5):
+                if wy == 0 and wx == 0:
+                    continue
+                out[..., k] = gray > np.roll(np.roll(gray, -wy, axis=0), -wx, axis=1)  # neighbour ((y+wy) mod h, (x+wx) mod w)
+                k += 1
+        return out
+    lc, rc = codes(gray8(l_bgr)), codes(gray8(r_bgr))
+    h, w = lc.shape[:2]
+    vol = np.full((max_dis_slabs, h, w), 80.0)
+    for d in range(max_dis_slabs):
+        if not right:
+            if d < w:
+                vol[d, :, d:] = (lc[:, d:] ^ rc[:, :w - d]).sum(-1)
+        else:
+            if d < w:
+                vol[d, :, :w - d] = (rc[:, :w - d] ^ lc[:, d:]).sum(-1)
+    return vol
+
+
 def plane_param(n, p):  # plane.h:25-34
     den = max(abs(n[2]), EPS)
     if n[2] < 0.0:
@@ -94,7 +123,8 @@ def plane_param(n, p):  # plane.h:25-34
 class PlaneCost:
     """PreSSPC (scale_num=0) / PreCSPC: pre_ss_pc.cc, pre_cs_pc.cc"""
 
-    def __init__(self, l, r, max_disp, wnd, scale_num, lam):
+    def __init__(self, l, r, max_disp, wnd, scale_num, lam, cc="GRD"):
+        build = cen_volume if cc == "CEN" else grd_volume
         self.cs = scale_num > 0
         S = scale_num if self.cs else 1
         self.half = wnd // 2
@@ -105,7 +135,7 @@ class PlaneCost:
                 self.img[v].append(pyrdown(self.img[v][s - 1]))
             w, h, d = self.dims[-1]
             self.dims.append(((w + 1) // 2, (h + 1) // 2, d // 2))
-        self.vol = [[grd_volume(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1) for s in range(S)] for v in (0, 1)]
+        self.vol = [[build(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1) for s in range(S)] for v in (0, 1)]
         self.max_cost = [[max(-1.0, float(self.vol[v][s].max())) for s in range(S)] for v in (0, 1)]
         if self.cs:
             M = np.zeros((S, S))

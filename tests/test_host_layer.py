@@ -73,4 +73,10 @@ def test_cli_matches_the_c_abi_path(gpu_ctx, mid_pair, tmp_path, use_cs, use_pp)
     np.testing.assert_array_equal(pngio.read_png(str(tmp_path / "ld.png")), want[0])
     np.testing.assert_array_equal(pngio.read_png(str(tmp_path / "rd.png")), want[1])
     # unknown cost name: error exit instead of the reference's NULL dereference
-    assert subprocess.call(args[:7] + ['--cc_name="CEN"'], stdout=subprocess.DEVNULL) == 1
+    assert subprocess.call(args[:7] + ['--cc_name="BSM"'], stdout=subprocess.DEVNULL) == 1
+    # the second CCMethod behind the same slot (every line of the reference's input.txt uses it)
+    subprocess.check_call(args[:7] + ['--cc_name=CEN', "--use_cs=false", "--seed=5", f"--l_dis_file={tmp_path}/lc.pgm", f"--r_dis_file={tmp_path}/rc.pgm"],
+                          stdout=subprocess.DEVNULL)
+    gpu_ctx.build_cost_cen(16, 35, 0, 0.0)
+    gpu_ctx.patchmatch(3, seed=5, schedule=0)
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "lc.pgm")), gpu_ctx.disparity_u8(0, 4))

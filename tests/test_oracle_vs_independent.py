@@ -141,3 +141,35 @@ def test_whole_patchmatch_against_second_restatement(scale_num, lam):
     pm.postprocess(); ref.postprocess()
     for v in (0, 1):
         np.testing.assert_array_equal(pm.dis(v), ref.dis[v])
+
+
+@pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (3, 0.3)])
+def test_census_volumes_and_costs(scale_num, lam):
+    """CenCC (cc/cen_cc.cc:4-137): 9x9 census with wrap-around borders, Hamming volumes, 80 outside; then GetPlaneCost."""
+    l, r = _tiny(31, 23, 9, 6)
+    pc = po.PlaneCost(l, r, 9, 7, scale_num, lam, cc="CEN")
+    ref = pyref.PlaneCost(l, r, 9, 7, scale_num, lam, cc="CEN")
+    for s in range(pc.levels):
+        for v in (0, 1):
+            np.testing.assert_array_equal(pc.volume(v, s), ref.vol[v][s])
+            assert pc.max_cost(v, s) == ref.max_cost[v][s] == 80.0
+    vol = pc.volume(0, 0)
+    assert np.all(vol[3, :, :3] == 80.0) and np.all(vol == np.floor(vol)) and vol.min() >= 0 and vol.max() <= 80
+    rng = np.random.default_rng(2)
+    for i in range(40):
+        x, y, v = int(rng.integers(0, 31)), int(rng.integers(0, 23)), int(rng.integers(0, 2))
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        prm = po.plane_param(n, [x, y, rng.uniform(0, 9)])
+        assert pc.cost(x, y, n, prm, v, po.SUM_SERIAL) == ref.cost(x, y, n, prm, v)
+
+
+def test_census_gray_contract():
+    """8U RGB2GRAY of OpenCV 2.4: (R*4899 + G*9617 + B*1868 + 8192) >> 14; white -> 255, pure channels -> 76/150/29."""
+    import ctypes as C
+    px = np.array([[[255, 255, 255], [0, 0, 255], [0, 255, 0], [255, 0, 0], [10, 20, 30]]], np.uint8)  # BGR
+    img = np.repeat(px, 9, axis=0)
+    pc = po.PlaneCost(img, img, 2, 3, 0, 0.0, cc="CEN")
+    g = ((px[..., 2].astype(int) * 4899 + px[..., 1].astype(int) * 9617 + px[..., 0].astype(int) * 1868 + 8192) >> 14)[0]
+    assert list(g) == [255, 76, 150, 29, 22]  # e.g. (30*4899 + 20*9617 + 10*1868 + 8192) >> 14 = 22
+    # identical views: zero cost wherever the other view is inside the image, 80 outside
+    assert np.all(pc.volume(0, 0)[0] == 0) and np.all(pc.volume(0, 0)[1][:, 0] == 80)
