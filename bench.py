@@ -74,20 +74,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: libcspm_hip has no CPU fallback")
+    backend = os.environ.get("CSPM_BENCH_BACKEND", "nccl")  # "gloo": only to exercise the N>1 control flow on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     cfg, l, r, gl, gr = synth.make_config(args.config, index=rank)
     w, h = cfg["w"], cfg["h"]
     d_l = torch.from_numpy(l).to(dev)
     d_r = torch.from_numpy(r).to(dev)
     d_out = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
-    ctx = cs.StereoContext(local_rank)
+    ctx = cs.StereoContext(dev_index)
     from crossscalepatchmatch_amd import capi
     ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
     sched = cs.SCHED_RASTER if args.schedule == "raster" else cs.SCHED_REDBLACK
@@ -119,7 +127,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     timing = ctx.timing()
