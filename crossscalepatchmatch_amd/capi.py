@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcspm_hip.so")
+_SO = os.environ.get("CSPM_LIB") or os.path.join(_HERE, "libcspm_hip.so")  # CSPM_LIB: an alternative build of the same library (tuning experiments)
 
 SCHED_RASTER, SCHED_REDBLACK = 0, 1
 RNG_PER_PIXEL, RNG_ROW_SHARED = 0, 1

@@ -175,3 +175,27 @@ def test_census_pipeline_bit_exact(gpu_ctx, mid_pair, scale_num, lam):
     l, r = gpu_ctx.postprocess(4)
     np.testing.assert_array_equal(l, pm.dis(0))
     np.testing.assert_array_equal(r, pm.dis(1))
+
+
+@pytest.mark.parametrize("w,h,D", [(1, 1, 2), (2, 1, 2), (1, 7, 3), (9, 2, 4), (5, 40, 4), (37, 3, 6), (20, 20, 25)])
+def test_degenerate_image_sizes(gpu_ctx, w, h, D):
+    """Ragged / tiny inputs: single pixels, single rows and columns, windows larger than the image, max_dis > width
+    (view propagation would index out of range in the reference; both sides skip those candidates)."""
+    rng = np.random.default_rng(w * 100 + h)
+    l = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    r = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    for sn, lam in ((0, 0.0), (5, 0.3)):
+        for sched in (po.SCHED_RASTER, po.SCHED_REDBLACK):
+            gpu_ctx.set_images(l, r)
+            gpu_ctx.build_cost_grd(D, 35, sn, lam)
+            pc = po.PlaneCost(l, r, D, 35, sn, lam)
+            pm = po.PatchMatch(l, r, D, 2)
+            pm.run(2, pc, True, seed=3, schedule=sched, sum_order=po.SUM_DEVICE)
+            gpu_ctx.patchmatch(2, seed=3, schedule=sched)
+            for v in (0, 1):
+                npar, cost = gpu_ctx.get_planes(v)
+                np.testing.assert_array_equal(npar[..., 3:], pm.planes(v)[..., 6:9])
+                np.testing.assert_array_equal(cost, pm.min_cost(v))
+            lo, ro = gpu_ctx.postprocess(2)
+            np.testing.assert_array_equal(lo, pm.dis(0))
+            np.testing.assert_array_equal(ro, pm.dis(1))
