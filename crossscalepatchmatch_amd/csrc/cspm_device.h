@@ -30,8 +30,9 @@ constexpr uint32_t kBorderPix = 0x00030303u;  // BORDER_THRES in B, G and R (cc/
 // + x-gradient, so one dwordx3 load fetches everything a tap needs of a pixel (the L1 address path
 // charges a wave64 load ~16 cycles whatever its width; the L1 return path charges bytes).
 struct __attribute__((packed, aligned(4))) PixG {
+  double g;      // x-gradient of the f32 gray image (grd_cc.cpp:70-77); GRD only.  First, so that a dwordx3 load puts it
+                 // in an even-aligned VGPR pair (64-bit operands need one; otherwise every load costs two v_mov)
   uint32_t pix;  // B | G<<8 | R<<16 (byte 3 = 0)
-  double g;      // x-gradient of the f32 gray image (grd_cc.cpp:70-77); GRD only
 };
 static_assert(sizeof(PixG) == 12, "PixG must be 12 bytes");
 

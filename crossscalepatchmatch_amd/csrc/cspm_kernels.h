@@ -38,7 +38,8 @@ struct Luts {
 
 // everything one level needs, wave-uniform
 struct LevelArgs {
-  int W, H, Wp, ox0, oy0, obase, ocen, dir;
+  int W, H, ox0, oy0;
+  int row12, obase12, ocen12, dir12;  // BYTE offsets into the 12-byte element arrays: row stride, window tap (0,0), centre, +-12
   double Dd, maxc;
   const PixG *px, *opx;
   const double *vol;
@@ -57,10 +58,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
 // one global_load_dwordx3 with a 32-bit byte offset (saddr + voffset addressing, no 64-bit address math)
-__device__ __forceinline__ u32x3 ld12(const PixG *base, int idx) {
-  return *reinterpret_cast<const u32x3_a4 *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)__mul24(idx, 12));
+__device__ __forceinline__ u32x3 ld12(const PixG *base, int byte_off) {
+  return *reinterpret_cast<const u32x3_a4 *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)byte_off);
 }
-__device__ __forceinline__ double g_of(const u32x3 &v) { return __hiloint2double((int)v.z, (int)v.y); }
+__device__ __forceinline__ double g_of(const u32x3 &v) { return __hiloint2double((int)v.y, (int)v.x); }
+__device__ __forceinline__ uint32_t pix_of(const u32x3 &v) { return v.z; }
 
 __device__ __forceinline__ void fill_tab(const Cost &cd, double *tab, int ox0, int oy0, double a, double b, double c, int lane) {
   wave_lds_fence();  // earlier reads of this table are done
@@ -80,17 +82,18 @@ __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut,
                                                 double b, double c, int lane) {
   const Level &L = cd.lv[s];
   LevelArgs A;
-  A.W = L.W; A.H = L.H; A.Wp = L.Wp;
+  A.W = L.W; A.H = L.H;
   A.ox0 = cx - cd.half; A.oy0 = cy - cd.half;
-  A.obase = A.oy0 * L.Wp + L.pad + A.ox0;  // element index of window tap (0,0); may be negative, used masked
-  A.ocen = cy * L.Wp + L.pad + cx;
-  A.dir = view == 0 ? -1 : 1;  // left view looks at x-d in the right image, right view at x+d in the left
+  A.row12 = L.Wp * 12;
+  A.obase12 = (A.oy0 * L.Wp + L.pad + A.ox0) * 12;  // window tap (0,0); may be negative, used masked
+  A.ocen12 = (cy * L.Wp + L.pad + cx) * 12;
+  A.dir12 = view == 0 ? -12 : 12;  // left view looks at x-d in the right image, right view at x+d in the left
   A.Dd = (double)L.D;
   A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
   A.px = L.px[view]; A.opx = L.px[1 - view];
   A.vol = L.vol[view];
   A.slab = (size_t)L.W * (size_t)L.H;
-  A.Ip = L.px[view][A.ocen].pix;
+  A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
   fill_tab(cd, lut.tab, A.ox0, A.oy0, a, b, c, lane);
   return A;
 }
@@ -99,7 +102,7 @@ __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut,
 // arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
 // TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
 __device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const u32x3 &o) {
-  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, o.x, 0u);
+  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, pix_of(o), 0u);
   const double grdDiff = __builtin_fmin(fabs(Gq - g_of(o)), 2.0);  // TAU_GRD
   return lut.a[sad] + (1 - 0.1) * grdDiff;                         // ALPHA*clrDiff + (1-ALPHA)*grdDiff
 }
@@ -124,16 +127,17 @@ struct TapOwn {
 };
 
 __device__ __forceinline__ TapOwn tap_own(const LevelArgs &A, const Luts &lut, int t) {
-  const int ocen = A.ocen, lutzero = kLutZero;
+  const int ocen = A.ocen12, lutzero = kLutZero;
   TapOwn w;
   const int dec = (int)lut.dec[t];
   w.dx = dec & 255;
   w.dy = (dec >> 8) & 255;
   w.ok = (dec >= 0) & ((unsigned)(A.oy0 + w.dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + w.dx) < (unsigned)A.W);
-  const int o0 = A.obase + __mul24(w.dy, A.Wp) + w.dx;  // 24-bit multiplies are full rate; v_mul_lo_u32 / v_mad_u64_u32 are not
+  // byte offset of the tap's element: two 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are not)
+  const int o0 = __mul24(w.dx, 12) + (__mul24(w.dy, A.row12) + A.obase12);
   w.o = w.ok ? o0 : ocen;                               // masked taps read the centre pixel ...
   w.P = ld12(A.px, w.o);
-  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, w.P.x, 0u);
+  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, pix_of(w.P), 0u);
   const int sum = w.ok ? sum0 : lutzero;                // ... with weight entry kLutZero = 0.0, so they add +0.0
   w.wgt = lut.w[sum];
   return w;
@@ -154,9 +158,9 @@ __device__ __forceinline__ double tap_plane(const Cost &cd, const LevelArgs &A, 
   double c0, c1;
   if (FUSED) {
     const double Gq = g_of(w.P);
-    const int of = w.o + __mul24(A.dir, f);
-    c0 = grd_cell(lut, w.P.x, Gq, ld12(A.opx, of));
-    c1 = grd_cell(lut, w.P.x, Gq, ld12(A.opx, of + A.dir));
+    const int of = w.o + __mul24(A.dir12, f);
+    c0 = grd_cell(lut, pix_of(w.P), Gq, ld12(A.opx, of));
+    c1 = grd_cell(lut, pix_of(w.P), Gq, ld12(A.opx, of + A.dir12));
   } else {
     const int hh = cd.half;
     const int dyc = w.ok ? w.dy : hh, dxc = w.ok ? w.dx : hh;
