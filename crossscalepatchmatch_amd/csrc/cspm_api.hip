@@ -245,6 +245,8 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     L.W = W; L.H = H; L.D = D;
     L.pad = D + 2;
     L.Wp = W + 2 * L.pad;
+    if ((long long)L.Wp * H * 12 >= (1LL << 31) || L.Wp * 12 >= (1 << 23))
+      return fail(c, CSPM_ERR_ARG, "image too large for the 32-bit / 24-bit element offsets of the tap engine");
     for (int v = 0; v < 2; ++v) {
       uint32_t *img;
       if ((rc = dalloc(c, &img, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
@@ -385,6 +387,7 @@ const cspm_pm_params kDefaultParams = {12345ULL, CSPM_SCHED_REDBLACK, 1, 4, CSPM
 int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
   if (!c) return CSPM_ERR_ARG;
   if (!c->cost_ready) return fail(c, CSPM_ERR_STATE, "no plane cost built (cspm_build_cost_grd / cspm_finish_cost)");
+  HIPCHK(c, hipSetDevice(c->device));
   if (!*p) *p = &kDefaultParams;
   if ((*p)->schedule != CSPM_SCHED_RASTER && (*p)->schedule != CSPM_SCHED_REDBLACK) return fail(c, CSPM_ERR_ARG, "bad schedule");
   if ((*p)->rb_neighbours != 2 && (*p)->rb_neighbours != 4) return fail(c, CSPM_ERR_ARG, "rb_neighbours must be 2 or 4");
