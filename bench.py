@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--volumes", action="store_true", help="materialise f64 cost volumes (reference data flow) instead of fused cells")
     ap.add_argument("--raster-launches", action="store_true", help="raster sweep as one launch per anti-diagonal instead of the persistent kernel")
+    ap.add_argument("--cc", default="GRD", choices=["GRD", "CEN"], help="cost function (BASELINE.json's metric is GRD; CEN for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket launches with hipEvents")
     args = ap.parse_args()
@@ -103,7 +104,7 @@ def main():
 
     def step():
         ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
-        ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
+        (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
         ctx.patchmatch(3, **pm_kw)
         for v in (0, 1):
             ctx.disparity_u8_device(v, cfg["dis_scale"], d_out[v].data_ptr())
@@ -137,18 +138,18 @@ def main():
         mpix = w * h * args.steps * world / dt / 1e6
         taps_launch = 2 * ctx.taps_per_view_pass()  # one refinement launch evaluates every pixel of both views once
         out = {
-            "metric": "Mpix/s disparity (GRD, use_cs=true)", "value": mpix, "unit": "Mpix/s", "n_gpus": world,
+            "metric": "Mpix/s disparity (%s, use_cs=true)" % args.cc, "value": mpix, "unit": "Mpix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w}x{h} max_dis={cfg['max_dis']} GRD scale_num={cfg['scale_num']} "
                                    f"reg_lambda={cfg['reg_lambda']} wnd=35 iters=3 (BASELINE.json configs[2] when C3)",
-                       "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule, "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds, "early_exit": not args.no_early_exit,
+                       "cc_name": args.cc, "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule, "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds, "early_exit": not args.no_early_exit,
                        "pairs_per_gpu": args.steps, "parallelism": f"{world} independent pair stream(s), one per GPU"},
         }
         ref = timing["refine"]
         traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), committed
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.config == "C3" and not args.volumes and os.path.exists(tpath):
+        if args.config == "C3" and args.cc == "GRD" and not args.volumes and os.path.exists(tpath):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         if ref["launches"]:
             avg_s = ref["ms"] / ref["launches"] / 1e3
@@ -165,7 +166,7 @@ def main():
             }
         out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
             out["cpu_baseline"] = cpu_baseline(cfg, l, r)
         # sanity of the result that was timed (not part of the timed region)
         dl = ctx.disparity_f64(0)

@@ -176,7 +176,8 @@ class StereoContext:
         self.set_option(OPT_GRD_VOLUMES, int(volumes))
         self._chk(self.L.cspm_build_cost_grd(self.p, max_dis, wnd_size, scale_num, reg_lambda))
 
-    def build_cost_cen(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):
+    def build_cost_cen(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False):
+        self.set_option(OPT_GRD_VOLUMES, int(volumes))
         self._chk(self.L.cspm_build_cost_cen(self.p, max_dis, wnd_size, scale_num, reg_lambda))
 
     def begin_cost(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):

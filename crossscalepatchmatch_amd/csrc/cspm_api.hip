@@ -42,6 +42,8 @@ struct cspm_ctx {
   std::vector<void *> cost_allocs;
   double *d_lut = nullptr, *d_lut_a = nullptr, *d_maxcost = nullptr;
   bool is_grd = false;           // cost built by cspm_build_cost_grd (gradients present)
+  bool is_cen = false;           // cost built by cspm_build_cost_cen (census codes present)
+  const uint32_t *cen_code[2][CSPM_MAX_LEVELS] = {{nullptr}};
   long long opt_grd_volumes = 0; // CSPM_OPT_GRD_VOLUMES
   unsigned long long *d_maxkeys = nullptr;
   // plane field
@@ -253,6 +255,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
       PixG *px;
       if ((rc = dalloc(c, &px, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
       L.px[v] = px;
+      L.pc[v] = nullptr;
       L.pix[v] = img;
       L.grd[v] = nullptr;
       L.vol[v] = nullptr;
@@ -304,8 +307,9 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   cd.lut = c->d_lut;
   cd.lut_a = c->d_lut_a;
   cd.max_cost = c->d_maxcost;
-  cd.fused = 0;
+  cd.fused = kSrcVolume;
   c->is_grd = false;
+  c->is_cen = false;
   c->cost_alloc = true;
   return CSPM_OK;
 }
@@ -395,12 +399,18 @@ int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
   return ensure_field(c);
 }
 
-#define LAUNCH_CS(kern, grid, block, shmem, ...)                                                          \
-  do {                                                                                                    \
-    if (c->cost.cs && c->cost.fused) hipLaunchKernelGGL((kern<true, true>), grid, block, shmem, c->stream, __VA_ARGS__);        \
-    else if (c->cost.cs) hipLaunchKernelGGL((kern<true, false>), grid, block, shmem, c->stream, __VA_ARGS__);                  \
-    else if (c->cost.fused) hipLaunchKernelGGL((kern<false, true>), grid, block, shmem, c->stream, __VA_ARGS__);               \
-    else hipLaunchKernelGGL((kern<false, false>), grid, block, shmem, c->stream, __VA_ARGS__);                                 \
+#define LAUNCH_CS(kern, grid, block, shmem, ...)                                                                  \
+  do {                                                                                                            \
+    const int src_ = c->cost.fused;                                                                               \
+    if (c->cost.cs) {                                                                                             \
+      if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<true, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);          \
+      else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<true, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);     \
+      else hipLaunchKernelGGL((kern<true, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                       \
+    } else {                                                                                                      \
+      if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<false, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);         \
+      else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<false, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);    \
+      else hipLaunchKernelGGL((kern<false, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                      \
+    }                                                                                                             \
   } while (0)
 
 int do_init(cspm_ctx *c, const cspm_pm_params *p) {
@@ -653,7 +663,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
     }
   }
   HIPCHK(c, hipGetLastError());
-  cd.fused = with_vol ? 0 : 1;
+  cd.fused = with_vol ? kSrcVolume : kSrcGrd;
   c->is_grd = true;
   return finish_cost(c);
 }
@@ -663,7 +673,8 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
 int cspm_build_cost_cen(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, true);
+  const bool with_vol = c->opt_grd_volumes != 0;
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol);
   if (rc) return rc;
   Cost &cd = c->cost;
   std::vector<void *> tmp;
@@ -672,24 +683,32 @@ int cspm_build_cost_cen(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
     return code;
   };
   for (int s = 0; s < cd.levels; ++s) {
-    const Level &L = cd.lv[s];
+    Level &L = cd.lv[s];
     const long long px = (long long)L.W * L.H, ppx = (long long)L.Wp * L.H;
-    uint8_t *gray[2];
     uint32_t *code[2];
     for (int v = 0; v < 2; ++v) {
-      if ((rc = dalloc(c, &gray[v], (size_t)px, &tmp)) || (rc = dalloc(c, &code[v], (size_t)px * 3, &tmp))) return done(rc);
+      uint8_t *gray;
+      PixC *pc;
+      if ((rc = dalloc(c, &gray, (size_t)px, &tmp)) || (rc = dalloc(c, &code[v], (size_t)px * 3, &c->cost_allocs)) ||
+          (rc = dalloc(c, &pc, (size_t)ppx, &c->cost_allocs)))
+        return done(rc);
+      L.pc[v] = pc;
+      c->cen_code[v][s] = code[v];
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_gray8<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H, gray[v]);
-      hipLaunchKernelGGL(k_census, dim3(ew_grid(px)), dim3(256), 0, c->stream, gray[v], L.W, L.H, code[v]);
+      hipLaunchKernelGGL(k_gray8<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H, gray);
+      hipLaunchKernelGGL(k_census, dim3(ew_grid(px)), dim3(256), 0, c->stream, gray, L.W, L.H, code[v]);
+      hipLaunchKernelGGL(k_make_aos_cen, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], code[v], L.W, L.H, L.Wp, L.pad, pc);
       hipLaunchKernelGGL(k_make_aos, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)nullptr, ppx, (PixG *)L.px[v]);
     }
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 2; ++v) {  // volumes when asked for, their max (pre_cs_pc.cc:75-82) always
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid(px * (L.D + 1))), dim3(256), 0, c->stream, code[0], code[1], L.W, L.H, L.D + 1, v,
+      hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid(px * (L.D + 1))), dim3(256), 0, c->stream, code[0], code[1], L.W, L.H, 0, L.D + 1, v,
                          (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
     }
   }
   HIPCHK(c, hipGetLastError());
+  cd.fused = with_vol ? kSrcVolume : kSrcCen;
+  c->is_cen = true;
   return done(finish_cost(c));
 }
 
@@ -718,8 +737,8 @@ int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
     hipLaunchKernelGGL(k_census, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, gray[v], w, h, code[v]);
   }
   if ((rc = dalloc(c, &vol, px * maxDis, &tmp))) return done(rc);
-  hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, code[0], code[1], w, h, maxDis, right_view, vol,
-                     (unsigned long long *)nullptr);
+  hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, code[0], code[1], w, h, 0, maxDis, right_view,
+                     vol, (unsigned long long *)nullptr);
   if (hipMemcpyAsync(vol_out, vol, sizeof(double) * px * maxDis, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)
     return done(fail(c, CSPM_ERR_HIP, "census volume kernel failed"));
@@ -743,7 +762,7 @@ int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, doubl
 
 int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double *slab, size_t stride_elems) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc || c->is_grd || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || c->is_cen || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   if (view < 0 || view > 1 || level < 0 || level >= c->cost.levels || !slab) return fail(c, CSPM_ERR_ARG, "bad view/level/slab");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D || stride_elems < (size_t)L.W) return fail(c, CSPM_ERR_ARG, "bad slab index or stride");
@@ -757,7 +776,7 @@ int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double 
 
 int cspm_finish_cost(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc || c->is_grd || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || c->is_cen || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
   for (int s = 0; s < c->cost.levels; ++s)
     for (int v = 0; v < 2; ++v) {
@@ -805,9 +824,13 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CSPM_OK;
   }
-  // fused GRD cost: materialise the requested slab with the volume kernel
+  // fused cost: materialise the requested slab with the volume kernel
   double *tmp;
   HIPCHK(c, hipMalloc((void **)&tmp, sizeof(double) * px));
+  if (c->is_cen)
+    hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, c->cen_code[0][level], c->cen_code[1][level], L.W,
+                       L.H, d, 1, view, tmp, (unsigned long long *)nullptr);
+  else
   hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
                      SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, d, 1, view, tmp,
                      (unsigned long long *)nullptr);

@@ -36,10 +36,22 @@ struct __attribute__((packed, aligned(4))) PixG {
 };
 static_assert(sizeof(PixG) == 12, "PixG must be 12 bytes");
 
+// census flavour of the element (CenCC, cc/cen_cc.cc): 80-bit code + colour; bit 31 of `pix` marks the pad cells,
+// whose cost is CENCUS_BIT whatever the own code is (cen_cc.cc:56-62)
+struct __attribute__((aligned(16))) PixC {
+  uint32_t code[3];
+  uint32_t pix;
+};
+static_assert(sizeof(PixC) == 16, "PixC must be 16 bytes");
+
+// where the PatchMatch kernels get their cell costs from
+enum { kSrcVolume = 0, kSrcGrd = 1, kSrcCen = 2 };
+
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
   int Wp, pad;
-  const PixG *px[2];      // H rows of Wp
+  const PixG *px[2];      // H rows of Wp (volume and fused-GRD sources)
+  const PixC *pc[2];      // H rows of Wp (fused-census source)
   const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
   const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only
   const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; null when fused
@@ -48,7 +60,7 @@ struct Level {
 
 struct Cost {
   int cs;      // 0: PreSSPC::GetPlaneCost, 1: PreCSPC::GetPlaneCost
-  int fused;   // 1: GRD cell costs are computed on the fly from pix/grd, 0: read from vol
+  int fused;   // kSrcVolume: cells are read from vol; kSrcGrd / kSrcCen: computed on the fly from px / pc
   int levels;
   int half;    // half_wnd_
   int n;       // 2*half+1

@@ -11,10 +11,11 @@
 // per pixel (k_spatial_diag), because a diagonal has only <= min(W,H) independent pixels.
 //
 // Cell costs come from one of two sources, selected at compile time:
-//   FUSED = true : GRD cell cost computed on the fly from the padded images + gradients (bit-identical
+//   SRC = kSrcGrd: GRD cell cost computed on the fly from the padded images + gradients (bit-identical
 //                  to reading GrdCC's volume, cc/grd_cc.cpp:4-35,60-154); nothing but ~12 B/pixel per
 //                  view and level is ever read, so the working set stays in L2 / Infinity Cache.
-//   FUSED = false: cost volumes in HBM (any CCMethod plugin; what the reference's PreSSPC/PreCSPC do).
+//   SRC = kSrcCen: census / Hamming cell cost computed on the fly from 80-bit codes (cc/cen_cc.cc:47-66).
+//   SRC = kSrcVolume: cost volumes in HBM (any CCMethod plugin; what the reference's PreSSPC/PreCSPC do).
 //
 // Summation order ("SLOT256", mirrored by the oracle): tap t is accumulated in t order into slot
 // t%256 (= accumulator (t/64)%4 of lane t%64); slots are reduced as (p0+p1)+(p2+p3) per lane, then an
@@ -39,9 +40,10 @@ struct Luts {
 // everything one level needs, wave-uniform
 struct LevelArgs {
   int W, H, ox0, oy0;
-  int row12, obase12, ocen12, dir12;  // BYTE offsets into the 12-byte element arrays: row stride, window tap (0,0), centre, +-12
+  int row12, obase12, ocen12, dir12;  // BYTE offsets into the element arrays (12-byte PixG / 16-byte PixC): row stride,
+                                      // window tap (0,0), centre, +- one element
   double Dd, maxc;
-  const PixG *px, *opx;
+  const char *px, *opx;               // own / other view elements
   const double *vol;
   size_t slab;
   uint32_t Ip;
@@ -57,12 +59,18 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
-// one global_load_dwordx3 with a 32-bit byte offset (saddr + voffset addressing, no 64-bit address math)
-__device__ __forceinline__ u32x3 ld12(const PixG *base, int byte_off) {
-  return *reinterpret_cast<const u32x3_a4 *>(reinterpret_cast<const char *>(base) + (size_t)(unsigned)byte_off);
+// One element with ONE global load and a 32-bit byte offset (saddr + voffset addressing, no 64-bit address math):
+// PixG = dwordx3 {g.lo, g.hi, pix}, PixC = dwordx4 {code0, code1, code2, pix}.  Held as 4 dwords either way.
+template <int SRC>
+__device__ __forceinline__ uint4 ld_elem(const char *base, int byte_off) {
+  if (SRC == kSrcCen) return *reinterpret_cast<const uint4 *>(base + (size_t)(unsigned)byte_off);
+  const u32x3 v = *reinterpret_cast<const u32x3_a4 *>(base + (size_t)(unsigned)byte_off);
+  return uint4{v.x, v.y, v.z, 0u};
 }
-__device__ __forceinline__ double g_of(const u32x3 &v) { return __hiloint2double((int)v.y, (int)v.x); }
-__device__ __forceinline__ uint32_t pix_of(const u32x3 &v) { return v.z; }
+template <int SRC> constexpr int elem_size() { return SRC == kSrcCen ? 16 : 12; }
+template <int SRC>
+__device__ __forceinline__ uint32_t pix_of(const uint4 &v) { return SRC == kSrcCen ? v.w : v.z; }
+__device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double((int)v.y, (int)v.x); }
 
 __device__ __forceinline__ void fill_tab(const Cost &cd, double *tab, int ox0, int oy0, double a, double b, double c, int lane) {
   wave_lds_fence();  // earlier reads of this table are done
@@ -78,22 +86,29 @@ __device__ __forceinline__ void fill_tab(const Cost &cd, double *tab, int ox0, i
 //   tab[kTabSize+dy] = plane_b * q_y + plane_c  (q_disp_y, pre_cs_pc.cc:155)
 // so that a tap's q_disp is one add of two LDS reads instead of two int->f64 converts, two multiplies
 // and two adds -- bit-identical, each table entry is rounded exactly like the expression it replaces.
+template <int SRC>
 __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut, int s, int view, int cx, int cy, double a,
                                                 double b, double c, int lane) {
   const Level &L = cd.lv[s];
+  constexpr int E = elem_size<SRC>();
   LevelArgs A;
   A.W = L.W; A.H = L.H;
   A.ox0 = cx - cd.half; A.oy0 = cy - cd.half;
-  A.row12 = L.Wp * 12;
-  A.obase12 = (A.oy0 * L.Wp + L.pad + A.ox0) * 12;  // window tap (0,0); may be negative, used masked
-  A.ocen12 = (cy * L.Wp + L.pad + cx) * 12;
-  A.dir12 = view == 0 ? -12 : 12;  // left view looks at x-d in the right image, right view at x+d in the left
+  A.row12 = L.Wp * E;
+  A.obase12 = (A.oy0 * L.Wp + L.pad + A.ox0) * E;  // window tap (0,0); may be negative, used masked
+  A.ocen12 = (cy * L.Wp + L.pad + cx) * E;
+  A.dir12 = view == 0 ? -E : E;  // left view looks at x-d in the right image, right view at x+d in the left
   A.Dd = (double)L.D;
   A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
-  A.px = L.px[view]; A.opx = L.px[1 - view];
+  if (SRC == kSrcCen) {
+    A.px = reinterpret_cast<const char *>(L.pc[view]); A.opx = reinterpret_cast<const char *>(L.pc[1 - view]);
+    A.Ip = L.pc[view][cy * L.Wp + L.pad + cx].pix;
+  } else {
+    A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
+    A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
+  }
   A.vol = L.vol[view];
   A.slab = (size_t)L.W * (size_t)L.H;
-  A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
   fill_tab(cd, lut.tab, A.ox0, A.oy0, a, b, c, lane);
   return A;
 }
@@ -101,10 +116,18 @@ __device__ __forceinline__ LevelArgs make_level(const Cost &cd, const Luts &lut,
 // myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
 // arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
 // TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
-__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const u32x3 &o) {
-  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, pix_of(o), 0u);
+__device__ __forceinline__ double grd_cell(const Luts &lut, uint32_t Iq, double Gq, const uint4 &o) {
+  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, pix_of<kSrcGrd>(o), 0u);
   const double grdDiff = __builtin_fmin(fabs(Gq - g_of(o)), 2.0);  // TAU_GRD
   return lut.a[sad] + (1 - 0.1) * grdDiff;                         // ALPHA*clrDiff + (1-ALPHA)*grdDiff
+}
+// CenCC cell (cc/cen_cc.cc:54-62): Hamming distance of the two 80-bit codes, CENCUS_BIT = 80 when the other view's
+// pixel is outside the image (pad cells carry bit 31 in `pix`)
+__device__ __forceinline__ double cen_cell(const uint4 &q, const uint4 &o) {
+  const int eighty = 80;
+  const int ham = __popc(q.x ^ o.x) + __popc(q.y ^ o.y) + __popc(q.z ^ o.z);
+  const int cnt = ((int)o.w < 0) ? eighty : ham;
+  return (double)cnt;
 }
 
 // v_cvt_i32_f64 saturates and maps NaN to 0; written as asm because (int)double is undefined out of range.
@@ -122,10 +145,11 @@ __device__ __forceinline__ int cvt_i32_sat(double x) {
 struct TapOwn {
   int o, dx, dy;
   bool ok;
-  u32x3 P;     // own pixel: colour, gradient
+  uint4 P;     // own element: gradient + colour (GRD / volume) or census code + colour
   double wgt;  // lookup_exp_[|dB|+|dG|+|dR|] (:161-164); 0 for taps outside the window / image
 };
 
+template <int SRC>
 __device__ __forceinline__ TapOwn tap_own(const LevelArgs &A, const Luts &lut, int t) {
   const int ocen = A.ocen12, lutzero = kLutZero;
   TapOwn w;
@@ -134,17 +158,17 @@ __device__ __forceinline__ TapOwn tap_own(const LevelArgs &A, const Luts &lut, i
   w.dy = (dec >> 8) & 255;
   w.ok = (dec >= 0) & ((unsigned)(A.oy0 + w.dy) < (unsigned)A.H) & ((unsigned)(A.ox0 + w.dx) < (unsigned)A.W);
   // byte offset of the tap's element: two 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are not)
-  const int o0 = __mul24(w.dx, 12) + (__mul24(w.dy, A.row12) + A.obase12);
+  const int o0 = __mul24(w.dx, elem_size<SRC>()) + (__mul24(w.dy, A.row12) + A.obase12);
   w.o = w.ok ? o0 : ocen;                               // masked taps read the centre pixel ...
-  w.P = ld12(A.px, w.o);
-  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, pix_of(w.P), 0u);
+  w.P = ld_elem<SRC>(A.px, w.o);
+  const int sum0 = (int)__builtin_amdgcn_sad_u8(A.Ip, pix_of<SRC>(w.P), 0u);
   const int sum = w.ok ? sum0 : lutzero;                // ... with weight entry kLutZero = 0.0, so they add +0.0
   w.wgt = lut.w[sum];
   return w;
 }
 
 // plane-dependent half: tab = the candidate's tables (tab[dx] = a*qx, tab[kTabSize+dy] = b*qy+c)
-template <bool FUSED>
+template <int SRC>
 __device__ __forceinline__ double tap_plane(const Cost &cd, const LevelArgs &A, const Luts &lut, const double *tab, const TapOwn &w) {
   const int one = 1;
   const double maxc = A.maxc;
@@ -156,11 +180,15 @@ __device__ __forceinline__ double tap_plane(const Cost &cd, const LevelArgs &A, 
   const int f = valid ? f0 : one;
   const double floor_wgt = (double)(f + 1) - q_disp;             // :171-172
   double c0, c1;
-  if (FUSED) {
+  if (SRC == kSrcGrd) {
     const double Gq = g_of(w.P);
     const int of = w.o + __mul24(A.dir12, f);
-    c0 = grd_cell(lut, pix_of(w.P), Gq, ld12(A.opx, of));
-    c1 = grd_cell(lut, pix_of(w.P), Gq, ld12(A.opx, of + A.dir12));
+    c0 = grd_cell(lut, pix_of<SRC>(w.P), Gq, ld_elem<SRC>(A.opx, of));
+    c1 = grd_cell(lut, pix_of<SRC>(w.P), Gq, ld_elem<SRC>(A.opx, of + A.dir12));
+  } else if (SRC == kSrcCen) {
+    const int of = w.o + __mul24(A.dir12, f);
+    c0 = cen_cell(w.P, ld_elem<SRC>(A.opx, of));
+    c1 = cen_cell(w.P, ld_elem<SRC>(A.opx, of + A.dir12));
   } else {
     const int hh = cd.half;
     const int dyc = w.ok ? w.dy : hh, dxc = w.ok ? w.dx : hh;
@@ -173,10 +201,10 @@ __device__ __forceinline__ double tap_plane(const Cost &cd, const LevelArgs &A, 
   return w.wgt * tmp;                                            // :176
 }
 
-template <bool FUSED>
+template <int SRC>
 __device__ __forceinline__ double tap_term(const Cost &cd, const LevelArgs &A, const Luts &lut, int t) {
-  const TapOwn w = tap_own(A, lut, t);
-  return tap_plane<FUSED>(cd, A, lut, lut.tab, w);
+  const TapOwn w = tap_own<SRC>(A, lut, t);
+  return tap_plane<SRC>(cd, A, lut, lut.tab, w);
 }
 
 // Cheap wave-wide LOWER-BOUND sum for the early-exit test: f32 DPP reduction (6 VALU instructions, no
@@ -198,7 +226,7 @@ __device__ __forceinline__ float wave_lower_bound(double part) {
 // One level, one wave: returns the level sum (identical in all lanes) or -1.0 once
 // base + partial*mul >= thresh is proven (all terms are >= 0: monotone, so the candidate is rejected).
 // The proof uses the cheap lower bound after every round of 256 taps and the exact sum at the level end.
-template <bool FUSED>
+template <int SRC>
 __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A, const Luts &lut, double base, double mul,
                                              double thresh, bool use_thresh, int lane) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -208,10 +236,10 @@ __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A,
   const float need = use_thresh ? (float)(((thresh - base) / mul) * 1.000001) : 0.0f;
   for (int i = 0; i < rounds; ++i) {
     const int t = i * 256 + lane;
-    const double t0 = tap_term<FUSED>(cd, A, lut, t);
-    const double t1 = tap_term<FUSED>(cd, A, lut, t + 64);
-    const double t2 = tap_term<FUSED>(cd, A, lut, t + 128);
-    const double t3 = tap_term<FUSED>(cd, A, lut, t + 192);
+    const double t0 = tap_term<SRC>(cd, A, lut, t);
+    const double t1 = tap_term<SRC>(cd, A, lut, t + 64);
+    const double t2 = tap_term<SRC>(cd, A, lut, t + 128);
+    const double t3 = tap_term<SRC>(cd, A, lut, t + 192);
     a0 += t0; a1 += t1; a2 += t2; a3 += t3;
     if (i == rounds - 1) break;
     if (use_thresh && wave_lower_bound((a0 + a1) + (a2 + a3)) > need) return -1.0;
@@ -223,13 +251,13 @@ __device__ __forceinline__ double level_cost(const Cost &cd, const LevelArgs &A,
 
 // Aggregated plane cost at (x,y); +inf when the candidate is proven not to beat `thresh`.
 // (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param().
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, int view, int x, int y, double nx, double ny,
                                              double nz, double pa, double pb, double pc, double thresh, bool use_thresh,
                                              int lane) {
   if (!CS) {
-    const LevelArgs A = make_level(cd, lut, 0, view, x, y, pa, pb, pc, lane);
-    const double r = level_cost<FUSED>(cd, A, lut, 0.0, 1.0, thresh, use_thresh, lane);
+    const LevelArgs A = make_level<SRC>(cd, lut, 0, view, x, y, pa, pb, pc, lane);
+    const double r = level_cost<SRC>(cd, A, lut, 0.0, 1.0, thresh, use_thresh, lane);
     return r < 0.0 ? __builtin_inf() : r;
   }
   double cost = 0.0;
@@ -246,8 +274,8 @@ __device__ __forceinline__ double eval_plane(const Cost &cd, const Luts &lut, in
     dot += nz * cur_disp;
     const double c = dot / denom;
     const double wgt = cd.lv[s].wgt;
-    const LevelArgs A = make_level(cd, lut, s, view, cur_x, cur_y, a, b, c, lane);
-    const double sc = level_cost<FUSED>(cd, A, lut, cost, wgt, thresh, use_thresh, lane);
+    const LevelArgs A = make_level<SRC>(cd, lut, s, view, cur_x, cur_y, a, b, c, lane);
+    const double sc = level_cost<SRC>(cd, A, lut, cost, wgt, thresh, use_thresh, lane);
     if (sc < 0.0) return __builtin_inf();
     cost += sc * wgt;  // :182
     cur_y /= 2;        // :183-185
@@ -299,7 +327,7 @@ __device__ __forceinline__ void store_plane(const Field &f, long long i, double 
 // ------------------------------------------------------------------------------------------------
 // cspm_plane_cost_batch: batched GetPlaneCost on explicit (x,y,plane) tuples -- the parity hook.
 // ------------------------------------------------------------------------------------------------
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, int n, const int *__restrict__ xy,
                                                            const double *__restrict__ np, double *__restrict__ out) {
   __shared__ LutMem<kEvalBlock / kWave> s_lut;
@@ -309,14 +337,14 @@ __global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, in
   const int lane = threadIdx.x & 63;
   const int x = xy[2 * e], y = xy[2 * e + 1];
   const double *p = np + 6 * e;
-  const double c = eval_plane<CS, FUSED>(cd, lut, view, x, y, p[0], p[1], p[2], p[3], p[4], p[5], kDoubleMax, false, lane);
+  const double c = eval_plane<CS, SRC>(cd, lut, view, x, y, p[0], p[1], p[2], p[3], p[4], p[5], kDoubleMax, false, lane);
   if (lane == 0) out[e] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
 // CSPatchMatch::InitRandomPlane  (cs_patchmatch.cc:115-148)
 // ------------------------------------------------------------------------------------------------
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
   __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
@@ -345,14 +373,14 @@ __global__ __launch_bounds__(kEvalBlock) void k_init(Cost cd, Pm pm) {
   const double nx = r0 * inv, ny = r1 * inv, nz = r2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)y, rand_dis, a, b, c);  // :141-142
-  const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, nx, ny, nz, a, b, c, kDoubleMax, false, lane);  // :143-144
+  const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, nx, ny, nz, a, b, c, kDoubleMax, false, lane);  // :143-144
   if (lane == 0) store_plane(pm.f[v], i, nx, ny, nz, a, b, c, cost);
 }
 
 // ------------------------------------------------------------------------------------------------
 // CSPatchMatch::PlaneRefinement, one halving step  (cs_patchmatch.cc:303-344)
 // ------------------------------------------------------------------------------------------------
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter, int step, double z_iter, double n_iter) {
   __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
@@ -379,7 +407,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter,
   const double nx = d0 * inv, ny = d1 * inv, nz = d2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)y, pz, a, b, c);                // :330
-  const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, nx, ny, nz, a, b, c, cur_min, pm.use_thresh != 0, lane);
+  const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, nx, ny, nz, a, b, c, cur_min, pm.use_thresh != 0, lane);
   if (cost < cur_min && lane == 0) store_plane(f, i, nx, ny, nz, a, b, c, cost);  // :335-338
 }
 
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter,
 // ------------------------------------------------------------------------------------------------
 struct Cand { double nx, ny, nz, a, b, c; };
 
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int colour, int inc, int nb) {
   __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
@@ -412,7 +440,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
     if (nxs[k] < 0 || nxs[k] >= pm.W || nys[k] < 0 || nys[k] >= pm.H) continue;
     const long long j = (long long)nys[k] * pm.W + nxs[k];
     const Cand cand{f.nx[j], f.ny[j], f.nz[j], f.a[j], f.b[j], f.c[j]};
-    const double cost = eval_plane<CS, FUSED>(cd, lut, v, x, y, cand.nx, cand.ny, cand.nz, cand.a, cand.b, cand.c, best_cost,
+    const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, cand.nx, cand.ny, cand.nz, cand.a, cand.b, cand.c, best_cost,
                                               pm.use_thresh != 0, lane);
     if (cost < best_cost) { best_cost = cost; best = cand; changed = true; }
   }
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // (:198-212); the first sweep row has only the former (:178-186), the first column only the latter
 // (:189-195).  No early exit: both candidate costs are needed in full when accepted.
 // ------------------------------------------------------------------------------------------------
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
   __shared__ LutMem<kDiagBlock / kWave> s_lut;
   __shared__ double s_part[2][CSPM_MAX_LEVELS][4][kWave];
@@ -457,20 +485,20 @@ __global__ __launch_bounds__(kDiagBlock) void k_spatial_diag(Cost cd, Pm pm, int
     for (int s = 0; s < levels; ++s) {
       double pa = c.a, pb = c.b, pc = c.c;
       if (CS) plane_param(c.nx, c.ny, c.nz, (double)cur_x, (double)cur_y, cur_disp, pa, pb, pc);
-      const LevelArgs A = make_level(cd, lut, s, v, cur_x, cur_y, pa, pb, pc, lane);
+      const LevelArgs A = make_level<SRC>(cd, lut, s, v, cur_x, cur_y, pa, pb, pc, lane);
       double acc = 0.0;
       const int rounds = cd.rounds;
       int i = 0;
       for (; i + 5 <= rounds; i += 5) {  // 5 independent taps per trip: their loads are issued together
         const int t = i * 256 + blk * 64 + lane;
-        const double t0 = tap_term<FUSED>(cd, A, lut, t);
-        const double t1 = tap_term<FUSED>(cd, A, lut, t + 256);
-        const double t2 = tap_term<FUSED>(cd, A, lut, t + 512);
-        const double t3 = tap_term<FUSED>(cd, A, lut, t + 768);
-        const double t4 = tap_term<FUSED>(cd, A, lut, t + 1024);
+        const double t0 = tap_term<SRC>(cd, A, lut, t);
+        const double t1 = tap_term<SRC>(cd, A, lut, t + 256);
+        const double t2 = tap_term<SRC>(cd, A, lut, t + 512);
+        const double t3 = tap_term<SRC>(cd, A, lut, t + 768);
+        const double t4 = tap_term<SRC>(cd, A, lut, t + 1024);
         acc += t0; acc += t1; acc += t2; acc += t3; acc += t4;
       }
-      for (; i < rounds; ++i) acc += tap_term<FUSED>(cd, A, lut, i * 256 + blk * 64 + lane);
+      for (; i < rounds; ++i) acc += tap_term<SRC>(cd, A, lut, i * 256 + blk * 64 + lane);
       s_part[cand][s][blk][lane] = acc;
       cur_y /= 2; cur_x /= 2; cur_disp /= 2.0;
     }
@@ -554,15 +582,15 @@ __device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int
 // i.e. over the same window: one pass computes the plane-independent half of every tap once and the
 // plane-dependent half twice.  NC = number of candidates present (2 except on the first sweep row / column).
 // Returns exact SLOT256 sums, identical in all lanes.
-template <bool FUSED, int NC>
+template <int SRC, int NC>
 __device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs &A, const Luts &lut, int t_first, int t_step,
                                                 int t_end, const double *tab0, const double *tab1, double acc0[4], double acc1[4]) {
   for (int t = t_first; t < t_end; t += t_step) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const TapOwn w = tap_own(A, lut, t + 64 * u);
-      acc0[u] += tap_plane<FUSED>(cd, A, lut, tab0, w);
-      if (NC == 2) acc1[u] += tap_plane<FUSED>(cd, A, lut, tab1, w);
+      const TapOwn w = tap_own<SRC>(A, lut, t + 64 * u);
+      acc0[u] += tap_plane<SRC>(cd, A, lut, tab0, w);
+      if (NC == 2) acc1[u] += tap_plane<SRC>(cd, A, lut, tab1, w);
     }
   }
 }
@@ -571,7 +599,7 @@ __device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs 
 // -> 4 waves, one per SLOT256 accumulator block.  Every wave handles both candidates.
 constexpr int kSweepMaxWaves = 8;
 
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kSweepMaxWaves * kWave, 4) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
   __shared__ LutMem<kSweepMaxWaves, 2> s_lut;
   __shared__ double s_part[2][4][kWave];        // single-scale: per-lane partials of the 4 accumulator blocks
@@ -640,26 +668,26 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, 4) void k_spatial_sweep(Cos
         for (int s = 0; s < wave; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
         double pa, pb, pc;
         plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pa, pb, pc);  // :144-149
-        const LevelArgs A = make_level(cd, lut, wave, v, cur_x, cur_y, pa, pb, pc, lane);
+        const LevelArgs A = make_level<SRC>(cd, lut, wave, v, cur_x, cur_y, pa, pb, pc, lane);
         if (both) {
           plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
           fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, pa, pb, pc, lane);
-          level_cost_pair<FUSED, 2>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
+          level_cost_pair<SRC, 2>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
         } else {
-          level_cost_pair<FUSED, 1>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
+          level_cost_pair<SRC, 1>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
         }
         const double s0 = wave_sum((a0[0] + a0[1]) + (a0[2] + a0[3]));
         const double s1 = both ? wave_sum((a1[0] + a1[1]) + (a1[2] + a1[3])) : s0;
         if (lane == 0) { s_lvl[0][wave] = s0; s_lvl[1][wave] = s1; }
       } else {
         // single scale: wave = accumulator block; tap t = q*256 + wave*64 + lane, one accumulator per lane
-        const LevelArgs A = make_level(cd, lut, 0, v, x, y, c0.a, c0.b, c0.c, lane);
+        const LevelArgs A = make_level<SRC>(cd, lut, 0, v, x, y, c0.a, c0.b, c0.c, lane);
         if (both) fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, c1.a, c1.b, c1.c, lane);
         double p0 = 0.0, p1 = 0.0;
         for (int q = 0; q < cd.rounds; ++q) {
-          const TapOwn w = tap_own(A, lut, q * 256 + wave * 64 + lane);
-          p0 += tap_plane<FUSED>(cd, A, lut, tab0, w);
-          if (both) p1 += tap_plane<FUSED>(cd, A, lut, tab1, w);
+          const TapOwn w = tap_own<SRC>(A, lut, q * 256 + wave * 64 + lane);
+          p0 += tap_plane<SRC>(cd, A, lut, tab0, w);
+          if (both) p1 += tap_plane<SRC>(cd, A, lut, tab1, w);
         }
         s_part[0][wave][lane] = p0;
         s_part[1][wave][lane] = both ? p1 : p0;
@@ -717,7 +745,7 @@ struct ViewCand {
   int *cx;      // target column
 };
 
-template <bool CS, bool FUSED>
+template <bool CS, int SRC>
 __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc) {
   __shared__ LutMem<kEvalBlock / kWave> s_lut;
   const Luts lut = load_luts(cd, s_lut);
@@ -738,7 +766,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v,
   if (cor_x >= 0 && cor_x < pm.W) {
     plane_param(nx, ny, nz, (double)cor_x, (double)y, disp, a, b, c);     // :263-265
     const double thr = dst.cost[(long long)y * pm.W + cor_x];
-    cost = eval_plane<CS, FUSED>(cd, lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, pm.use_thresh != 0, lane);  // :266-267
+    cost = eval_plane<CS, SRC>(cd, lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, pm.use_thresh != 0, lane);  // :266-267
   }
   if (lane == 0) {
     vc.cost[i] = cost;
@@ -929,6 +957,23 @@ __global__ void k_make_aos(const uint32_t *__restrict__ pix, const double *__res
   e.g = grd ? grd[i] : 0.0;
   out[i] = e;
 }
+// census elements: code of the pixel (unpadded W*H x 3 words) + colour; pad cells are flagged in bit 31 of pix
+__global__ void k_make_aos_cen(const uint32_t *__restrict__ pix, const uint32_t *__restrict__ code, int W, int H, int Wp, int pad,
+                               PixC *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Wp * H) return;
+  const int y = (int)(i / Wp), x = (int)(i - (long long)y * Wp) - pad;
+  PixC e;
+  if (x >= 0 && x < W) {
+    const uint32_t *c = code + 3 * ((size_t)y * W + x);
+    e.code[0] = c[0]; e.code[1] = c[1]; e.code[2] = c[2];
+    e.pix = pix[i];
+  } else {
+    e.code[0] = e.code[1] = e.code[2] = 0u;
+    e.pix = pix[i] | 0x80000000u;
+  }
+  out[i] = e;
+}
 // unpadded W*H packed pixels -> padded level (pad cells = border constant)
 __global__ void k_pad_u32(const uint32_t *__restrict__ src, int W, int H, int Wp, int pad, uint32_t *__restrict__ dst) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1109,13 +1154,13 @@ __global__ void k_census(const uint8_t *__restrict__ gray, int W, int H, uint32_
   code[3 * i] = w[0]; code[3 * i + 1] = w[1]; code[3 * i + 2] = w[2];
 }
 // cen_cc.cc:47-66 / 114-133: Hamming distance of the two codes, CENCUS_BIT = 80 where the other view is outside
-__global__ __launch_bounds__(256) void k_cen_volume(const uint32_t *__restrict__ lc, const uint32_t *__restrict__ rc, int W, int H, int nd,
-                                                    int right_view, double *__restrict__ vol, unsigned long long *max_key) {
+__global__ __launch_bounds__(256) void k_cen_volume(const uint32_t *__restrict__ lc, const uint32_t *__restrict__ rc, int W, int H, int d0,
+                                                    int nd, int right_view, double *__restrict__ vol, unsigned long long *max_key) {
   const long long slab = (long long)W * H, cells = slab * nd;
   double best = -1.7976931348623157e308;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
-    const int d = (int)(i / slab);
-    const long long o = i - (long long)d * slab;
+    const int d = d0 + (int)(i / slab);
+    const long long o = i - (long long)(d - d0) * slab;
     const int y = (int)(o / W), x = (int)(o - (long long)y * W);
     const int xo = right_view ? x + d : x - d;
     double cost = 80.0;
@@ -1123,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_cen_volume(const uint32_t *__restrict__
       const uint32_t *a = (right_view ? rc : lc) + 3 * o, *b = (right_view ? lc : rc) + 3 * ((long long)y * W + xo);
       cost = (double)(__popc(a[0] ^ b[0]) + __popc(a[1] ^ b[1]) + __popc(a[2] ^ b[2]));
     }
-    vol[i] = cost;
+    if (vol) vol[i] = cost;
     best = cost > best ? cost : best;
   }
   unsigned long long key = f64_key(best);

@@ -72,7 +72,7 @@ int cspm_set_images_device(cspm_ctx *ctx, const void *d_l_bgr, const void *d_r_b
  * (cc/grd_cc.cpp:60-154), max_cost, scale weights, exp LUT -- all on the device. */
 int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
 /* options (set before cspm_build_cost_grd).
- * CSPM_OPT_GRD_VOLUMES: 0 (default) = GRD cell costs are recomputed on the fly from the images and
+ * CSPM_OPT_GRD_VOLUMES (applies to the GRD and the census cost): 0 (default) = cell costs are recomputed on the fly from the images and
  * gradients inside the PatchMatch kernels (bit-identical to reading GrdCC's volumes, no 1-30 GB cost
  * volume in HBM); 1 = materialise the d-major f64 volumes exactly as PreCSPC does (pre_cs_pc.cc:50-73)
  * and read them. */
@@ -82,8 +82,9 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * per sweep; same results, kept as a cross-check). */
 #define CSPM_OPT_RASTER_LAUNCHES 2
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
-/* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census / Hamming cost volumes of
- * every level built on the device and kept in HBM (f64, d-major, as the reference stores them). */
+/* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on
+ * the device; Hamming cells are computed on the fly from the codes (default) or materialised as f64 volumes
+ * (CSPM_OPT_GRD_VOLUMES = 1), exactly like the GRD cost. */
 int cspm_build_cost_cen(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
 /* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
  * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */

@@ -143,15 +143,16 @@ def test_golden_cost_fixture(gpu_ctx):
             np.testing.assert_allclose(got, g[f"{name}_v{v}_serial"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
 @pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (5, 0.3)])
-def test_census_cost(gpu_ctx, request, pairname, scale_num, lam):
+def test_census_cost(gpu_ctx, request, pairname, scale_num, lam, volumes):
     """CenCC (cc/cen_cc.cc:4-137) on the device: volumes of every level, max_cost, batched GetPlaneCost, host boundary."""
     import ctypes as C
     import crossscalepatchmatch_amd as cs
     pair = request.getfixturevalue(pairname)
     gpu_ctx.set_images(pair["l"], pair["r"])
-    gpu_ctx.build_cost_cen(pair["max_dis"], 35, scale_num, lam)
+    gpu_ctx.build_cost_cen(pair["max_dis"], 35, scale_num, lam, volumes=volumes)
     pc = po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], 35, scale_num, lam, cc="CEN")
     for s in range(pc.levels):
         for v in (0, 1):
@@ -162,7 +163,7 @@ def test_census_cost(gpu_ctx, request, pairname, scale_num, lam):
     got = gpu_ctx.plane_cost_batch(0, xy, np.concatenate([norm, param], 1))
     want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], 0, po.SUM_DEVICE) for i in range(800)])
     np.testing.assert_array_equal(got, want)
-    if scale_num == 0:  # CCMethod::buildCV / buildRightCV on caller-owned CV_64FC3 buffers
+    if scale_num == 0 and not volumes:  # CCMethod::buildCV / buildRightCV on caller-owned CV_64FC3 buffers
         L, lib = cs.load_library(), po.lib()
         h, w, D = pair["h"], pair["w"], pair["max_dis"] + 1
         l = np.ascontiguousarray(pair["l"][..., ::-1].astype(np.float64) + rng.uniform(-0.49, 0.49, (h, w, 3)))

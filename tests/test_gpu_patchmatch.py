@@ -161,11 +161,12 @@ def test_raster_sweep_persistent_equals_per_diagonal_launches(gpu_ctx, request, 
         gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
 
 
+@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (5, 0.3)])
-def test_census_pipeline_bit_exact(gpu_ctx, mid_pair, scale_num, lam):
+def test_census_pipeline_bit_exact(gpu_ctx, mid_pair, scale_num, lam, volumes):
     """--cc_name=CEN: the whole PatchMatch + post-processing with the census cost, reference raster order."""
     gpu_ctx.set_images(mid_pair["l"], mid_pair["r"])
-    gpu_ctx.build_cost_cen(mid_pair["max_dis"], 35, scale_num, lam)
+    gpu_ctx.build_cost_cen(mid_pair["max_dis"], 35, scale_num, lam, volumes=volumes)
     pc = po.PlaneCost(mid_pair["l"], mid_pair["r"], mid_pair["max_dis"], 35, scale_num, lam, cc="CEN")
     pm = po.PatchMatch(mid_pair["l"], mid_pair["r"], mid_pair["max_dis"], 4)
     pm.run(3, pc, False, seed=11, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
