@@ -80,3 +80,56 @@ def test_cli_matches_the_c_abi_path(gpu_ctx, mid_pair, tmp_path, use_cs, use_pp)
     gpu_ctx.build_cost_cen(16, 35, 0, 0.0)
     gpu_ctx.patchmatch(3, seed=5, schedule=0)
     np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "lc.pgm")), gpu_ctx.disparity_u8(0, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_cs", [0, 1])
+def test_foreign_ccmethod_plugin_through_the_cpp_layer(gpu_ctx, small_pair, tmp_path, use_cs):
+    """A CCMethod written by a plugin author (tests/helpers/foreign_cc_check.cc) drives PreSSPC/PreCSPC + CSPatchMatch:
+    the host layer calls it level by level on CV_64FC3 Mats and uploads its volumes (pre_cs_pc.cc:57-74)."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "foreign_cc_check")
+    pkg = os.path.join(ROOT, "crossscalepatchmatch_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "helpers", "foreign_cc_check.cc"),
+                           os.path.join(HOST, "host_impl.cc"), os.path.join(HOST, "image_io.cc"), "-L", pkg, "-lcspm_hip", "-lz",
+                           "-Wl,-rpath," + pkg])
+    l, r, D = small_pair["l"], small_pair["r"], small_pair["max_dis"]
+    pngio.write_pnm(str(tmp_path / "l.ppm"), l[..., ::-1])
+    pngio.write_pnm(str(tmp_path / "r.ppm"), r[..., ::-1])
+    txt = subprocess.check_output([exe, str(tmp_path / "l.ppm"), str(tmp_path / "r.ppm"), str(D), str(use_cs), str(tmp_path / "ol.pgm"),
+                                   str(tmp_path / "or.pgm")]).decode().split()
+    # the same cost function in numpy, fed to the oracle (volumes overwritten) and to the C ABI (slab upload)
+    sn = 3 if use_cs else 0
+    pc = po.PlaneCost(l, r, D, 35, sn, 0.3 if use_cs else 0.0)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.begin_cost(D, 35, sn, 0.3 if use_cs else 0.0)
+    for s in range(pc.levels):
+        w, h, Ds = pc.dims(s)
+        rgb = [pc.image(v, s)[..., ::-1].astype(np.float64) for v in (0, 1)]
+        for v in (0, 1):
+            vol = pc.volume(v, s)
+            for d in range(Ds + 1):
+                slab = np.full((h, w), 100.0)
+                if d < w:
+                    if v == 0:
+                        slab[:, d:] = np.abs(rgb[0][:, d:, 0] - rgb[1][:, :w - d, 0]) + 0.5 * np.abs(rgb[0][:, d:, 2] - rgb[1][:, :w - d, 2])
+                    else:
+                        slab[:, :w - d] = np.abs(rgb[1][:, :w - d, 0] - rgb[0][:, d:, 0]) + 0.5 * np.abs(rgb[1][:, :w - d, 2] - rgb[0][:, d:, 2])
+                vol[d] = slab
+                gpu_ctx.upload_cost_slab(v, s, d, slab)
+    pc.refresh_max_cost()
+    gpu_ctx.finish_cost()
+    # per-call GetPlaneCost through the C++ virtual == oracle (device order)
+    pts = [(0, 0, 0), (small_pair["w"] // 2, small_pair["h"] // 2, 1), (small_pair["w"] - 1, small_pair["h"] - 1, 0)]
+    for (x, y, v), got in zip(pts, txt):
+        n = np.array([0.1, -0.2, 0.97])
+        prm = po.plane_param(n, [x, y, 4.25])
+        assert float(got) == pc.cost(x, y, n, prm, v, po.SUM_DEVICE)
+    # whole PatchMatch with the plugin's volumes == oracle with the same volumes
+    pm = po.PatchMatch(l, r, D, 4)
+    pm.run(2, pc, False, seed=99, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "ol.pgm")), pm.dis(0))
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "or.pgm")), pm.dis(1))
