@@ -27,7 +27,7 @@ BYTES_PER_TAP = 19  # 3 B guide pixel + 2 x 8 B cost cells per w
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(cfg, l, r, budget_note=True):
+def cpu_baseline(cfg, l, r, device_index=0):
     """The oracle (kind "port": the reference itself needs OpenCV/gflags and cannot be built here) in
     reference order on a bounded centred crop of the same pair, on this box's host cores."""
     from oracle import pyoracle as po
@@ -42,7 +42,18 @@ def cpu_baseline(cfg, l, r, budget_note=True):
     pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL, threads=threads)
     dt = time.perf_counter() - t0
     taps = sum(pc.taps(x, y) for y in range(ch) for x in range(cw)) * (pm.evals() // (cw * ch))
+    # the north-star parity figure on the same crop: HIP path vs this CPU run (identical inputs, seeds, schedule)
+    import crossscalepatchmatch_amd as cs
+    g = cs.StereoContext(device_index)
+    g.set_images(lc, rc)
+    g.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    g.patchmatch(3, seed=12345, schedule=cs.SCHED_RASTER)
+    diff = [np.abs(g.disparity_f64(v) - pm.disp_f64(v)) for v in (0, 1)]
+    g.close()
     return {
+        "gpu_vs_cpu_bad0.5": float(np.mean([np.mean(d > 0.5) for d in diff])),
+        "gpu_vs_cpu_bad2.0": float(np.mean([np.mean(d > 2.0) for d in diff])),
+        "gpu_vs_cpu_max_abs_px": float(max(d.max() for d in diff)),
         "value": cw * ch / dt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
         "sample": f"centred {cw}x{ch} crop of the same pair, max_dis={cfg['max_dis']}, {cfg['scale_num']} levels, "
                   f"reference order (raster sweep, serial sum), OpenMP over rows of init/refinement as the reference; "
@@ -167,7 +178,7 @@ def main():
         out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
-            out["cpu_baseline"] = cpu_baseline(cfg, l, r)
+            out["cpu_baseline"] = cpu_baseline(cfg, l, r, dev_index)
         # sanity of the result that was timed (not part of the timed region)
         dl = ctx.disparity_f64(0)
         out["bad2_vs_gt_left"] = synth.bad_fraction(dl, gl, 2.0)
