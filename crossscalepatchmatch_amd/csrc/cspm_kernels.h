@@ -585,6 +585,20 @@ __device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int
 template <int SRC, int NC>
 __device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs &A, const Luts &lut, int t_first, int t_step,
                                                 int t_end, const double *tab0, const double *tab1, double acc0[4], double acc1[4]) {
+  if (t_end == 1280 && t_step == 256) {
+    // the usual 35x35 window: 5 rounds, fully unrolled so that the loads of later rounds are issued while earlier
+    // rounds compute -- a sweep pixel is latency-bound, and its latency is the length of the dependency chain
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const TapOwn w = tap_own<SRC>(A, lut, t_first + i * 256 + 64 * u);
+        acc0[u] += tap_plane<SRC>(cd, A, lut, tab0, w);
+        if (NC == 2) acc1[u] += tap_plane<SRC>(cd, A, lut, tab1, w);
+      }
+    }
+    return;
+  }
   for (int t = t_first; t < t_end; t += t_step) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -658,7 +672,11 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, 4) void k_spatial_sweep(Cos
         s_plane[0][0] = c0.nx; s_plane[0][1] = c0.ny; s_plane[0][2] = c0.nz; s_plane[0][3] = c0.a; s_plane[0][4] = c0.b; s_plane[0][5] = c0.c;
         s_plane[1][0] = c1.nx; s_plane[1][1] = c1.ny; s_plane[1][2] = c1.nz; s_plane[1][3] = c1.a; s_plane[1][4] = c1.b; s_plane[1][5] = c1.c;
       }
-      const bool both = have0 && have1;
+      // Result-preserving shortcut: once the sweep has passed over them, both predecessors very often hold bitwise
+      // the same plane (98 / 87 / 49 % of neighbours after sweeps 0 / 1 / 2 on the C3 pair).  The second evaluation
+      // would return the same bits as the first and `cost1 < min(cur, cost0)` would fail, so it is not computed.
+      const bool same01 = c0.nx == c1.nx && c0.ny == c1.ny && c0.nz == c1.nz && c0.a == c1.a && c0.b == c1.b && c0.c == c1.c;
+      const bool both = have0 && have1 && !same01;
       SWEEP_STAMP(3);
       double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
       if (CS) {
