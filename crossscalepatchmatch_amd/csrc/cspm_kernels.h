@@ -23,6 +23,11 @@
 #pragma once
 #include "cspm_device.h"
 
+// minimum waves per SIMD the register allocator leaves room for in the sweep kernel (2nd __launch_bounds__ argument)
+#ifndef CSPM_SWEEP_MINW
+#define CSPM_SWEEP_MINW 4
+#endif
+
 #pragma clang fp contract(off)
 
 namespace cspm {
@@ -614,7 +619,7 @@ __device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs 
 constexpr int kSweepMaxWaves = 8;
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kSweepMaxWaves * kWave, 4) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
+__global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
   __shared__ LutMem<kSweepMaxWaves, 2> s_lut;
   __shared__ double s_part[2][4][kWave];        // single-scale: per-lane partials of the 4 accumulator blocks
   __shared__ double s_lvl[2][CSPM_MAX_LEVELS];  // cross-scale: exact level sums
