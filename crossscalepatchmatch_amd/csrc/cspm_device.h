@@ -15,7 +15,10 @@ constexpr double kDoubleEps = 0.00000001;  // commfunc.h:26
 constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_limits<double>::max()
 constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
 constexpr int kLutZero = 767;              // entry forced to 0.0: masked taps read it, so they add wgt*tmp = +0.0
-constexpr int kTabSize = 128;              // per-wave tables a*qx / b*qy+c; 128 (not the 45 needed) keeps the two tables in different bank phases: 48 costs 6 %
+#ifndef CSPM_TABSIZE
+#define CSPM_TABSIZE 128
+#endif
+constexpr int kTabSize = CSPM_TABSIZE;              // per-wave tables a*qx / b*qy+c; 128 (not the 45 needed) keeps the two tables in different bank phases: 48 costs 6 %
 constexpr int kMaxRounds = 8;              // tap decode table in LDS: up to 2048 taps (window <= 45x45)
 constexpr int kWave = 64;
 constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup

@@ -617,10 +617,13 @@ __device__ __forceinline__ void level_cost_pair(const Cost &cd, const LevelArgs 
 // Work split inside a sweep workgroup: cross-scale -> one wave per pyramid level (`levels` waves); single-scale
 // -> 4 waves, one per SLOT256 accumulator block.  Every wave handles both candidates.
 constexpr int kSweepMaxWaves = 8;
+// the second candidate's tables live in the gaps of the first one's (entries 48..95 and kTabSize+48..): a window has
+// at most 45 columns / rows, so one 2 KB table block per wave serves both and a fourth workgroup fits in the CU's LDS
+constexpr int kTab1 = 48;
 
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
-  __shared__ LutMem<kSweepMaxWaves, 2> s_lut;
+  __shared__ LutMem<kSweepMaxWaves, 1> s_lut;
   __shared__ double s_part[2][4][kWave];        // single-scale: per-lane partials of the 4 accumulator blocks
   __shared__ double s_lvl[2][CSPM_MAX_LEVELS];  // cross-scale: exact level sums
   __shared__ double s_plane[2][6];
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spa
   const Luts lut = load_luts(cd, s_lut);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const double *tab0 = lut.tab, *tab1 = lut.tab + 2 * kTabSize;
+  const double *tab0 = lut.tab, *tab1 = lut.tab + kTab1;
   const int ndiag = pm.W + pm.H - 1;
   int k = 0;
   unsigned int next_item = 0;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spa
         const LevelArgs A = make_level<SRC>(cd, lut, wave, v, cur_x, cur_y, pa, pb, pc, lane);
         if (both) {
           plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
-          fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, pa, pb, pc, lane);
+          fill_tab(cd, lut.tab + kTab1, A.ox0, A.oy0, pa, pb, pc, lane);
           level_cost_pair<SRC, 2>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
         } else {
           level_cost_pair<SRC, 1>(cd, A, lut, lane, 256, cd.rounds * 256, tab0, tab1, a0, a1);
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spa
       } else {
         // single scale: wave = accumulator block; tap t = q*256 + wave*64 + lane, one accumulator per lane
         const LevelArgs A = make_level<SRC>(cd, lut, 0, v, x, y, c0.a, c0.b, c0.c, lane);
-        if (both) fill_tab(cd, lut.tab + 2 * kTabSize, A.ox0, A.oy0, c1.a, c1.b, c1.c, lane);
+        if (both) fill_tab(cd, lut.tab + kTab1, A.ox0, A.oy0, c1.a, c1.b, c1.c, lane);
         double p0 = 0.0, p1 = 0.0;
         for (int q = 0; q < cd.rounds; ++q) {
           const TapOwn w = tap_own<SRC>(A, lut, q * 256 + wave * 64 + lane);
