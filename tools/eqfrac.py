@@ -1,3 +1,4 @@
+"""debug: how often neighbouring pixels hold bitwise-identical planes before / after each raster sweep (C3 pair)."""
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np
 import crossscalepatchmatch_amd as cs
