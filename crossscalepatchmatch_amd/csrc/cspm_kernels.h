@@ -710,10 +710,19 @@ __global__ __launch_bounds__(kSweepMaxWaves * kWave, CSPM_SWEEP_MINW) void k_spa
         const LevelArgs A = make_level<SRC>(cd, lut, 0, v, x, y, c0.a, c0.b, c0.c, lane);
         if (both) fill_tab(cd, lut.tab + kTab1, A.ox0, A.oy0, c1.a, c1.b, c1.c, lane);
         double p0 = 0.0, p1 = 0.0;
-        for (int q = 0; q < cd.rounds; ++q) {
-          const TapOwn w = tap_own<SRC>(A, lut, q * 256 + wave * 64 + lane);
-          p0 += tap_plane<SRC>(cd, A, lut, tab0, w);
-          if (both) p1 += tap_plane<SRC>(cd, A, lut, tab1, w);
+        if (cd.rounds == 5) {  // the usual window: unrolled, all loads of the five taps in flight together
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const TapOwn w = tap_own<SRC>(A, lut, q * 256 + wave * 64 + lane);
+            p0 += tap_plane<SRC>(cd, A, lut, tab0, w);
+            if (both) p1 += tap_plane<SRC>(cd, A, lut, tab1, w);
+          }
+        } else {
+          for (int q = 0; q < cd.rounds; ++q) {
+            const TapOwn w = tap_own<SRC>(A, lut, q * 256 + wave * 64 + lane);
+            p0 += tap_plane<SRC>(cd, A, lut, tab0, w);
+            if (both) p1 += tap_plane<SRC>(cd, A, lut, tab1, w);
+          }
         }
         s_part[0][wave][lane] = p0;
         s_part[1][wave][lane] = both ? p1 : p0;
