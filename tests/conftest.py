@@ -41,6 +41,14 @@ def odd_pair():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # PyTorch bundles its own HIP runtime: when both live in one process, torch has to initialise first (bench.py and
+    # batch.py do the same); libcspm_hip.so then binds to the runtime that is already loaded.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     import crossscalepatchmatch_amd as cs
     ctx = cs.StereoContext(0)  # raises CspmError when the HIP library / device is missing: no fallback
     yield ctx

@@ -200,3 +200,39 @@ def test_degenerate_image_sizes(gpu_ctx, w, h, D):
             lo, ro = gpu_ctx.postprocess(2)
             np.testing.assert_array_equal(lo, pm.dis(0))
             np.testing.assert_array_equal(ro, pm.dis(1))
+
+
+def test_device_resident_io_stream_and_timing(gpu_ctx, small_pair):
+    """The entry points bench.py and the batch driver use: images already in HBM, a caller-provided HIP stream,
+    8-bit maps written to device memory, per-kernel-class hipEvent timing."""
+    import torch
+    import crossscalepatchmatch_amd as cs
+    pc, pm = _setup(gpu_ctx, small_pair, 5, 0.3)
+    pm.run(2, pc, False, seed=21, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    dev = torch.device("cuda", 0)
+    h, w = small_pair["h"], small_pair["w"]
+    d_l, d_r = torch.from_numpy(small_pair["l"]).to(dev), torch.from_numpy(small_pair["r"]).to(dev)
+    ctx = cs.StereoContext(0)
+    stream = torch.cuda.Stream(device=dev)
+    try:
+        ctx.set_stream(stream.cuda_stream)
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
+        ctx.build_cost_grd(small_pair["max_dis"], 35, 5, 0.3)
+        ctx.patchmatch(2, seed=21, schedule=cs.SCHED_RASTER)
+        outs = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
+        for v in (0, 1):
+            ctx.disparity_u8_device(v, 4, outs[v].data_ptr())
+        ctx.synchronize()
+        for v in (0, 1):
+            np.testing.assert_array_equal(outs[v].cpu().numpy(), pm.dis(v))
+        t = ctx.timing()
+        assert t["init"]["launches"] == 1 and t["init"]["evals"] == 2 * w * h
+        assert t["refine"]["launches"] == 2 * po.lib().csor_refine_steps(small_pair["max_dis"])
+        assert t["spatial"]["launches"] == 2 and t["view"]["launches"] == 4
+        assert all(t[k]["ms"] > 0 for k in ("grd", "init", "spatial", "view", "refine"))
+        assert ctx.taps_per_view_pass() == sum(pc.taps(x, y) for y in range(h) for x in range(w))
+        ctx.set_stream(0)
+    finally:
+        ctx.close()
