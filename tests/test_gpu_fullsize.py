@@ -132,3 +132,33 @@ def test_c5_full_resolution_runs(gpu_ctx):
     lo, ro = gpu_ctx.postprocess(cfg["dis_scale"])
     assert lo.shape == (2000, 3000) and lo.max() <= 255
     gpu_ctx.set_images(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8))  # release the big buffers
+
+
+def test_c3_persistent_sweep_vs_per_diagonal_launches(gpu_ctx, c3):
+    """Full-size stress of the inter-workgroup hand-off (per-pixel done flags, agent-scope atomics across the 8 XCDs):
+    the persistent sweep must give, repeatedly, exactly the plane field of the one-launch-per-diagonal sweep, whose
+    ordering is enforced by kernel boundaries."""
+    from crossscalepatchmatch_amd import capi
+    cfg, l, r, _, _ = c3
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    kw = dict(seed=77, schedule=0)
+    try:
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 1)
+        gpu_ctx.pm_init(**kw)
+        start = [gpu_ctx.get_planes(v) for v in (0, 1)]
+        for it in (0, 1):
+            gpu_ctx.pm_spatial(it, **kw)
+        want = [gpu_ctx.get_planes(v) for v in (0, 1)]
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
+        for rep in range(4):
+            for v in (0, 1):
+                gpu_ctx.set_planes(v, *start[v])
+            for it in (0, 1):
+                gpu_ctx.pm_spatial(it, **kw)
+            for v in (0, 1):
+                got = gpu_ctx.get_planes(v)
+                np.testing.assert_array_equal(got[0], want[v][0], err_msg=f"repetition {rep}, view {v}")
+                np.testing.assert_array_equal(got[1], want[v][1], err_msg=f"repetition {rep}, view {v}")
+    finally:
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
