@@ -29,26 +29,45 @@ def block_sizes(n_items, world):
 
 
 class HipPairFn:
-    """(l_bgr, r_bgr) torch uint8 tensors on the rank's GPU -> (l_dis, r_dis) torch uint8 tensors, via the C ABI."""
+    """(l_bgr, r_bgr) torch uint8 tensors on the rank's GPU -> (l_dis, r_dis) torch uint8 tensors, via the C ABI.
+
+    Stream ordering: libcspm runs on a stream of its own (a torch side stream handed to cspm_set_stream).  Before a pair
+    is enqueued that stream waits (device-side) for torch's current stream -- the one the NCCL/RCCL scatter was ordered
+    into by ProcessGroupNCCL.wait() -- so k_pack_bgr never reads a half-received input block; after the pair, torch's
+    current stream waits for the libcspm stream, so the gather that follows sees finished maps.  No host synchronisation
+    per pair."""
 
     def __init__(self, device_index):
+        import torch
         from .capi import StereoContext
+        self.device = torch.device("cuda", device_index)
         self.ctx = StereoContext(device_index)  # raises CspmError without libcspm_hip.so / a gfx950 device
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ctx.set_stream(self.stream.cuda_stream)
 
     def __call__(self, l, r, p):
         import torch
         h, w = int(p["h"]), int(p["w"])
+        assert l.is_cuda and l.device == self.device and l.is_contiguous() and r.is_contiguous()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         self.ctx.set_images_device(l.data_ptr(), r.data_ptr(), w, h, w * 3)
         self.ctx.build_cost_grd(int(p["max_dis"]), 35, int(p["scale_num"]), float(p["reg_lambda"]))
         self.ctx.patchmatch(int(p["iters"]), seed=int(p["seed"]), schedule=int(p["schedule"]))
         if int(p["use_pp"]):
-            lo, ro = self.ctx.postprocess(int(p["dis_scale"]))
+            lo, ro = self.ctx.postprocess(int(p["dis_scale"]))  # synchronises (host buffers)
             return torch.from_numpy(lo).to(l.device), torch.from_numpy(ro).to(l.device)
         out = [torch.empty((h, w), dtype=torch.uint8, device=l.device) for _ in range(2)]
         for v in (0, 1):
+            out[v].record_stream(self.stream)
             self.ctx.disparity_u8_device(v, int(p["dis_scale"]), out[v].data_ptr())
-        self.ctx.synchronize()
+        l.record_stream(self.stream)
+        r.record_stream(self.stream)
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return out[0], out[1]
+
+    def close(self):
+        self.ctx.synchronize()  # also reports a raster sweep that timed out
+        self.ctx.close()
 
 
 def run_batch(pairs, params, pair_fn, device="cpu", dist=None):
@@ -135,6 +154,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_batch(pairs, params, fn, device=f"cuda:{local_rank}", dist=dist if world > 1 else None)
+    fn.ctx.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -235,7 +235,7 @@ class StereoContext:
         return out
 
     # ---- PatchMatch ----
-    def params(self, seed=12345, schedule=SCHED_REDBLACK, rb_rounds=1, rb_neighbours=4, rng_mode=RNG_PER_PIXEL, early_exit=1):
+    def params(self, seed=12345, schedule=SCHED_RASTER, rb_rounds=1, rb_neighbours=4, rng_mode=RNG_PER_PIXEL, early_exit=1):
         return PmParams(seed, schedule, rb_rounds, rb_neighbours, rng_mode, early_exit)
 
     def patchmatch(self, iters=3, **kw):

@@ -26,13 +26,38 @@ struct TimingRec {
 
 }  // namespace
 
+// every extern "C" entry that touches HIP runs on the ctx's device and leaves the caller's current device as it found it
+struct DevGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;
+  }
+  ~DevGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// what the buffers of a cost object were sized for: an identical request reuses them (no hipMalloc / hipFree per pair)
+struct CostKey {
+  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1;
+  bool operator==(const CostKey &o) const {
+    return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind;
+  }
+};
+enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2 };
+
 struct cspm_ctx {
-  int device = 0;
+  int device = 0, ncu = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
   // images
   int W = 0, H = 0;
   uint32_t *img0[2] = {nullptr, nullptr};
+  uint8_t *stage = nullptr;  // host-image staging buffer (cspm_set_images), 3*W*H bytes, kept
+  size_t stage_bytes = 0;
   // cost object
   bool cost_alloc = false, cost_ready = false;
   Cost cost{};
@@ -40,6 +65,10 @@ struct cspm_ctx {
   double scale_wgt[CSPM_MAX_LEVELS] = {0};
   double host_max_cost[2 * CSPM_MAX_LEVELS] = {0};
   std::vector<void *> cost_allocs;
+  CostKey cost_key;
+  bool max_cost_fetched = false;  // host_max_cost mirrors d_maxcost
+  int *d_early_ok = nullptr;      // device flag: every max_cost (and, for uploaded volumes, every min) is >= 0
+  uint8_t *cen_gray[2][CSPM_MAX_LEVELS] = {{nullptr}};
   double *d_lut = nullptr, *d_lut_a = nullptr, *d_maxcost = nullptr;
   bool is_grd = false;           // cost built by cspm_build_cost_grd (gradients present)
   bool is_cen = false;           // cost built by cspm_build_cost_cen (census codes present)
@@ -151,6 +180,7 @@ void free_cost(cspm_ctx *c) {
   for (void *p : c->cost_allocs) (void)hipFree(p);
   c->cost_allocs.clear();
   c->cost_alloc = c->cost_ready = false;
+  c->cost_key = CostKey{};
   memset(&c->cost, 0, sizeof c->cost);
 }
 void free_field(cspm_ctx *c) {
@@ -177,11 +207,15 @@ void free_images(cspm_ctx *c) {
     if (c->img0[v]) (void)hipFree(c->img0[v]);
     c->img0[v] = nullptr;
   }
+  if (c->stage) (void)hipFree(c->stage);
+  c->stage = nullptr;
+  c->stage_bytes = 0;
   c->W = c->H = 0;
 }
 
-// pre_cs_pc.cc:86-109: scale_wgt[s] = inv(tridiag(lambda))(0,s); Mat::inv() = LU with partial pivoting
-// and reciprocal pivots (OpenCV 2.4 LUImpl), identity right-hand side.
+void small_inverse_row0(int S, const double A[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS], double *w);
+// pre_cs_pc.cc:86-109: scale_wgt[s] = inv(tridiag(lambda))(0,s); Mat::inv() = cv::invert(DECOMP_LU): closed form for
+// n <= 3, otherwise LU with partial pivoting and reciprocal pivots (OpenCV 2.4 LUImpl), identity right-hand side.
 int scale_weights(int S, double lambda, double *w) {
   if (S < 1 || S > CSPM_MAX_LEVELS) return -1;
   double A[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS] = {{0}}, B[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS] = {{0}};
@@ -191,6 +225,10 @@ int scale_weights(int S, double lambda, double *w) {
     if (s == 0) { A[s][s] = 1 + lambda; A[s][s + 1] = -lambda; }
     else if (s == S - 1) { A[s][s] = 1 + lambda; A[s][s - 1] = -lambda; }
     else { A[s][s] = 1 + 2 * lambda; A[s][s - 1] = -lambda; A[s][s + 1] = -lambda; }
+  }
+  if (S <= 3) {  // cv::invert's closed-form path
+    small_inverse_row0(S, A, w);
+    return 0;
   }
   const double eps = DBL_EPSILON * 100;
   for (int i = 0; i < S; ++i) {
@@ -220,112 +258,181 @@ int scale_weights(int S, double lambda, double *w) {
   return 0;
 }
 
-// allocate the (padded) pyramid images and, when `with_vol`, the cost volumes; fill Cost (everything
-// except gradients / volume contents / max_cost)
-int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol) {
-  if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
-  if (max_dis < 1 || wnd_size < 1 || wnd_size > 45 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
-    return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
-  free_cost(c);
+// cv::invert(DECOMP_LU) of OpenCV 2.4 takes a closed-form path for n <= 3 (det2 / det3 and cofactors times 1/det);
+// only the first row of the inverse is needed (pre_cs_pc.cc:105-108).  Restated from the OpenCV 2.4 sources
+// from memory -- not verifiable in this image.
+void small_inverse_row0(int S, const double A[CSPM_MAX_LEVELS][CSPM_MAX_LEVELS], double *w) {
+  if (S == 1) {
+    w[0] = 1. / A[0][0];
+  } else if (S == 2) {
+    double d = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    d = 1. / d;
+    w[0] = A[1][1] * d;
+    w[1] = -A[0][1] * d;
+  } else {
+    double d = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+               A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    d = 1. / d;
+    w[0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) * d;
+    w[1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * d;
+    w[2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * d;
+  }
+}
+
+// (re)run the pyramid of both views into the level images (pre_cs_pc.cc:36-55)
+void launch_pyramid(cspm_ctx *c) {
   Cost &cd = c->cost;
-  cd.cs = scale_num > 0;
-  cd.levels = cd.cs ? scale_num : 1;
-  cd.half = wnd_size / 2;
-  cd.n = 2 * cd.half + 1;
-  cd.T = cd.n * cd.n;
-  cd.groups = (cd.T + kWave - 1) / kWave;
-  cd.rounds = (cd.groups + 3) / 4;
-  if (cd.rounds > kMaxRounds) return fail(c, CSPM_ERR_ARG, "wnd_size too large (the tap decode table holds 2048 taps: wnd_size <= 45)");
-  c->max_dis = max_dis;
-  c->wnd = wnd_size;
-  int rc;
-  // pre_cs_pc.cc:36-55
-  int W = c->W, H = c->H, D = max_dis;
   for (int s = 0; s < cd.levels; ++s) {
-    if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
     Level &L = cd.lv[s];
-    L.W = W; L.H = H; L.D = D;
-    L.pad = D + 2;
-    L.Wp = W + 2 * L.pad;
-    if ((long long)L.Wp * H * 12 >= (1LL << 31) || L.Wp * 12 >= (1 << 23))
-      return fail(c, CSPM_ERR_ARG, "image too large for the 32-bit / 24-bit element offsets of the tap engine");
     for (int v = 0; v < 2; ++v) {
-      uint32_t *img;
-      if ((rc = dalloc(c, &img, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
-      PixG *px;
-      if ((rc = dalloc(c, &px, (size_t)L.Wp * H, &c->cost_allocs))) return rc;
-      L.px[v] = px;
-      L.pc[v] = nullptr;
-      L.pix[v] = img;
-      L.grd[v] = nullptr;
-      L.vol[v] = nullptr;
-      if (with_vol) {
-        double *vol;
-        if ((rc = dalloc(c, &vol, (size_t)(D + 1) * W * H, &c->cost_allocs))) return rc;
-        L.vol[v] = vol;
-      }
       Timed t(c, CSPM_K_MISC, 0);
+      uint32_t *img = const_cast<uint32_t *>(L.pix[v]);
       if (s == 0) {
-        hipLaunchKernelGGL(k_pad_u32, dim3(ew_grid((long long)L.Wp * H)), dim3(256), 0, c->stream, c->img0[v], W, H, L.Wp, L.pad, img);
+        hipLaunchKernelGGL(k_pad_u32, dim3(ew_grid((long long)L.Wp * L.H)), dim3(256), 0, c->stream, c->img0[v], L.W, L.H, L.Wp, L.pad, img);
       } else {
         const Level &P = cd.lv[s - 1];
-        hipLaunchKernelGGL(k_pyrdown, dim3(ew_grid((long long)L.Wp * H)), dim3(256), 0, c->stream, P.pix[v], P.W, P.H, P.Wp, P.pad,
-                           img, W, H, L.Wp, L.pad);
+        hipLaunchKernelGGL(k_pyrdown, dim3(ew_grid((long long)L.Wp * L.H)), dim3(256), 0, c->stream, P.pix[v], P.W, P.H, P.Wp, P.pad,
+                           img, L.W, L.H, L.Wp, L.pad);
       }
     }
   }
-  // scale weights (pre_cs_pc.cc:86-109), exp LUT (pre_cs_pc.cc:111-114), GRD colour-term LUT (grd_cc.cpp:8-18)
+}
+
+// allocate the (padded) pyramid images, the per-kind side arrays (gradients / census codes) and, when `with_vol`, the
+// cost volumes; fill Cost (everything except gradients / volume contents / max_cost).  An identical request (same
+// image size, max_dis, window, levels, kind, volumes) reuses every buffer: no allocator call, no host synchronisation.
+int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind) {
+  if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
+  if (max_dis < 1 || wnd_size < 1 || wnd_size > 45 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
+    return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
+  CostKey key;
+  key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
+  const bool reuse = c->cost_alloc && key == c->cost_key;
+  if (!reuse) free_cost(c);
+  Cost &cd = c->cost;
+  c->cost_ready = false;
+  c->max_cost_fetched = false;
+  int rc;
+  if (!reuse) {
+    cd.cs = scale_num > 0;
+    cd.levels = cd.cs ? scale_num : 1;
+    cd.half = wnd_size / 2;
+    cd.n = 2 * cd.half + 1;
+    cd.T = cd.n * cd.n;
+    cd.groups = (cd.T + kWave - 1) / kWave;
+    cd.rounds = (cd.groups + 3) / 4;
+    if (cd.rounds > kMaxRounds) return fail(c, CSPM_ERR_ARG, "wnd_size too large (the tap decode table holds 2048 taps: wnd_size <= 45)");
+    c->max_dis = max_dis;
+    c->wnd = wnd_size;
+    // pre_cs_pc.cc:36-55
+    int W = c->W, H = c->H, D = max_dis;
+    for (int s = 0; s < cd.levels; ++s) {
+      if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
+      Level &L = cd.lv[s];
+      L.W = W; L.H = H; L.D = D;
+      L.pad = D + 2;
+      L.Wp = W + 2 * L.pad;
+      if ((long long)L.Wp * H * 12 >= (1LL << 31) || L.Wp * 12 >= (1 << 23))
+        return fail(c, CSPM_ERR_ARG, "image too large for the 32-bit / 24-bit element offsets of the tap engine");
+      const size_t px = (size_t)W * H, ppx = (size_t)L.Wp * H;
+      for (int v = 0; v < 2; ++v) {
+        uint32_t *img;
+        if ((rc = dalloc(c, &img, ppx, &c->cost_allocs))) return rc;
+        PixG *pxg;
+        if ((rc = dalloc(c, &pxg, ppx, &c->cost_allocs))) return rc;
+        L.px[v] = pxg;
+        L.pc[v] = nullptr;
+        L.pix[v] = img;
+        L.grd[v] = nullptr;
+        L.vol[v] = nullptr;
+        if (with_vol) {
+          double *vol;
+          if ((rc = dalloc(c, &vol, (size_t)(D + 1) * px, &c->cost_allocs))) return rc;
+          L.vol[v] = vol;
+        }
+        if (kind == kKindGrd) {
+          double *g;
+          if ((rc = dalloc(c, &g, ppx, &c->cost_allocs))) return rc;
+          L.grd[v] = g;
+        } else if (kind == kKindCen) {
+          uint8_t *gray;
+          uint32_t *code;
+          PixC *pc;
+          if ((rc = dalloc(c, &gray, px, &c->cost_allocs)) || (rc = dalloc(c, &code, px * 3, &c->cost_allocs)) ||
+              (rc = dalloc(c, &pc, ppx, &c->cost_allocs)))
+            return rc;
+          c->cen_gray[v][s] = gray;
+          c->cen_code[v][s] = code;
+          L.pc[v] = pc;
+        }
+      }
+    }
+    double lut[2 * kLutSize];
+    for (int i = 0; i < kLutSize; ++i) {
+      lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
+      double clrDiff = (double)i;          // sum of three |lC-rC|, an exact integer
+      clrDiff *= 0.3333333333;
+      clrDiff = clrDiff > 10.0 ? 10.0 : clrDiff;  // TAU_CLR
+      lut[kLutSize + i] = 0.1 * clrDiff;   // ALPHA * clrDiff
+    }
+    if ((rc = dalloc(c, &c->d_lut, 2 * kLutSize, &c->cost_allocs))) return rc;
+    c->d_lut_a = c->d_lut + kLutSize;
+    if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
+    if ((rc = dalloc(c, &c->d_early_ok, 1, &c->cost_allocs))) return rc;
+    {  // tap decode table: t -> (dx, dy) of the linearised window, bit 31 marks the padding taps t >= T
+      std::vector<uint32_t> dec((size_t)cd.rounds * 256);
+      for (int t = 0; t < cd.rounds * 256; ++t) dec[t] = t < cd.T ? (uint32_t)((t % cd.n) | ((t / cd.n) << 8)) : 0x80000000u;
+      uint32_t *d_dec;
+      if ((rc = dalloc(c, &d_dec, dec.size(), &c->cost_allocs))) return rc;
+      HIPCHK(c, hipMemcpy(d_dec, dec.data(), dec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      cd.dec = d_dec;
+    }
+    if ((rc = dalloc(c, &c->d_maxkeys, 4 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
+    HIPCHK(c, hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    cd.lut = c->d_lut;
+    cd.lut_a = c->d_lut_a;
+    cd.max_cost = c->d_maxcost;
+    cd.early_ok = c->d_early_ok;
+    c->cost_key = key;
+    c->cost_alloc = true;
+  }
+  launch_pyramid(c);
+  // scale weights (pre_cs_pc.cc:86-109): host-side, per call (reg_lambda is not part of the buffer key)
   if (cd.cs) {
     if (scale_weights(cd.levels, reg_lambda, c->scale_wgt)) return fail(c, CSPM_ERR_ARG, "singular regularisation matrix");
   } else {
     c->scale_wgt[0] = 1.0;
   }
   for (int s = 0; s < cd.levels; ++s) cd.lv[s].wgt = c->scale_wgt[s];
-  double lut[2 * kLutSize];
-  for (int i = 0; i < kLutSize; ++i) {
-    lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
-    double clrDiff = (double)i;          // sum of three |lC-rC|, an exact integer
-    clrDiff *= 0.3333333333;
-    clrDiff = clrDiff > 10.0 ? 10.0 : clrDiff;  // TAU_CLR
-    lut[kLutSize + i] = 0.1 * clrDiff;   // ALPHA * clrDiff
-  }
-  if ((rc = dalloc(c, &c->d_lut, 2 * kLutSize, &c->cost_allocs))) return rc;
-  c->d_lut_a = c->d_lut + kLutSize;
-  if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
-  {  // tap decode table: t -> (dx, dy) of the linearised window, bit 31 marks the padding taps t >= T
-    std::vector<uint32_t> dec((size_t)cd.rounds * 256);
-    for (int t = 0; t < cd.rounds * 256; ++t) dec[t] = t < cd.T ? (uint32_t)((t % cd.n) | ((t / cd.n) << 8)) : 0x80000000u;
-    uint32_t *d_dec;
-    if ((rc = dalloc(c, &d_dec, dec.size(), &c->cost_allocs))) return rc;
-    HIPCHK(c, hipMemcpy(d_dec, dec.data(), dec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    cd.dec = d_dec;
-  }
-  if ((rc = dalloc(c, &c->d_maxkeys, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice, c->stream));
+  // max keys [0, 2L) start at 0 (= below every key), min keys [2L, 4L) at all-ones
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // lut[] is a stack buffer
-  cd.lut = c->d_lut;
-  cd.lut_a = c->d_lut_a;
-  cd.max_cost = c->d_maxcost;
+  HIPCHK(c, hipMemsetAsync(c->d_maxkeys + 2 * CSPM_MAX_LEVELS, 0xFF, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
   cd.fused = kSrcVolume;
   c->is_grd = false;
   c->is_cen = false;
-  c->cost_alloc = true;
   return CSPM_OK;
 }
 
-int finish_cost(cspm_ctx *c) {
+// max_cost of every level/view from the reduced keys and the early-exit licence, all on the device: no host round trip.
+// The early-exit proof (cspm_kernels.h level_cost) needs every term of the sum to be >= 0: scale weights (checked here),
+// cell costs (GRD and census cells are >= 0 by construction; an uploaded volume is checked through its reduced MIN).
+int finish_cost(cspm_ctx *c, bool check_min) {
   Cost &cd = c->cost;
-  hipLaunchKernelGGL(k_keys_to_f64, dim3(1), dim3(64), 0, c->stream, c->d_maxkeys, c->d_maxcost, 2 * CSPM_MAX_LEVELS, -1.0);
+  int wgt_ok = 1;
+  for (int s = 0; s < cd.levels; ++s)
+    if (!(c->scale_wgt[s] >= 0.0)) wgt_ok = 0;
+  hipLaunchKernelGGL(k_finish_cost, dim3(1), dim3(64), 0, c->stream, c->d_maxkeys, c->d_maxcost, 2 * CSPM_MAX_LEVELS, cd.levels, -1.0,
+                     wgt_ok, check_min ? 1 : 0, c->d_early_ok);
+  HIPCHK(c, hipGetLastError());
+  c->cost_ready = true;
+  return CSPM_OK;
+}
+
+int fetch_max_cost(cspm_ctx *c) {
+  if (c->max_cost_fetched) return CSPM_OK;
   HIPCHK(c, hipMemcpyAsync(c->host_max_cost, c->d_maxcost, sizeof c->host_max_cost, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  cd.early_ok = 1;
-  for (int s = 0; s < cd.levels; ++s) {
-    if (!(c->scale_wgt[s] >= 0.0)) cd.early_ok = 0;
-    for (int v = 0; v < 2; ++v)
-      if (!(c->host_max_cost[v * CSPM_MAX_LEVELS + s] >= 0.0)) cd.early_ok = 0;
-  }
-  c->cost_ready = true;
+  c->max_cost_fetched = true;
   return CSPM_OK;
 }
 
@@ -347,6 +454,7 @@ int ensure_field(cspm_ctx *c) {
   }
   // persistent sweep state: control words, per-pixel done epochs (zero = never), diagonal start table
   if ((rc = dalloc(c, &c->d_sweep_ctrl, 2, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
   if ((rc = dalloc(c, &c->d_sweep_done, 2 * n, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_done, 0, sizeof(unsigned int) * 2 * n, c->stream));
   c->sweep_epoch = 0;
@@ -369,29 +477,33 @@ Pm make_pm(cspm_ctx *c, const cspm_pm_params *p) {
   pm.W = c->W; pm.H = c->H; pm.max_dis = c->max_dis;
   pm.seed = p->seed;
   pm.rng_row_shared = p->rng_mode == CSPM_RNG_ROW_SHARED;
-  pm.use_thresh = (p->early_exit && c->cost.early_ok) ? 1 : 0;
+  pm.use_thresh = p->early_exit ? 1 : 0;  // and-ed with the cost object's device-side licence (Cost::early_ok) in the kernels
   pm.f[0] = c->f[0];
   pm.f[1] = c->f[1];
   return pm;
 }
 
-// after a persistent sweep: its bounded spins raise ctrl[1] instead of hanging
+// A persistent sweep's bounded spins raise the STICKY error word ctrl[1] instead of hanging (later sweeps then drain at
+// once).  It is looked at by every call that synchronises with the host anyway (cspm_synchronize, the getters, the
+// single-phase entry cspm_pm_spatial): cspm_patchmatch itself stays asynchronous.
 int check_sweep(cspm_ctx *c) {
   if (!c->sweep_pending) return CSPM_OK;
   unsigned int ctrl[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(ctrl, c->d_sweep_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sweep_pending = false;
-  if (ctrl[1]) return fail(c, CSPM_ERR_HIP, "raster sweep timed out waiting for a predecessor pixel (inter-workgroup hand-off)");
+  if (ctrl[1]) {
+    (void)hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream);
+    return fail(c, CSPM_ERR_HIP, "raster sweep timed out waiting for a predecessor pixel (inter-workgroup hand-off)");
+  }
   return CSPM_OK;
 }
 
-const cspm_pm_params kDefaultParams = {12345ULL, CSPM_SCHED_REDBLACK, 1, 4, CSPM_RNG_PER_PIXEL, 1};
+const cspm_pm_params kDefaultParams = {12345ULL, CSPM_SCHED_RASTER, 1, 4, CSPM_RNG_PER_PIXEL, 1};
 
 int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
   if (!c) return CSPM_ERR_ARG;
   if (!c->cost_ready) return fail(c, CSPM_ERR_STATE, "no plane cost built (cspm_build_cost_grd / cspm_finish_cost)");
-  HIPCHK(c, hipSetDevice(c->device));
   if (!*p) *p = &kDefaultParams;
   if ((*p)->schedule != CSPM_SCHED_RASTER && (*p)->schedule != CSPM_SCHED_REDBLACK) return fail(c, CSPM_ERR_ARG, "bad schedule");
   if ((*p)->rb_neighbours != 2 && (*p)->rb_neighbours != 4) return fail(c, CSPM_ERR_ARG, "rb_neighbours must be 2 or 4");
@@ -460,9 +572,8 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       }
     }
 #endif
-    HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, sizeof(unsigned int), c->stream));  // the claim counter; ctrl[1] is sticky
+    int ncu = c->ncu;
     const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * 6);  // more than fit is harmless: unclaimed work is all a late workgroup needs
     const unsigned waves = c->cost.cs ? (unsigned)c->cost.levels : 4u;  // one wave per level, or per accumulator block
     {
@@ -538,13 +649,15 @@ int cspm_create(cspm_ctx **out, int device) {
   if (e != hipSuccess || n <= 0)
     return fail(nullptr, CSPM_ERR_HIP, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count=0"));
   if (device < 0 || device >= n) return fail(nullptr, CSPM_ERR_ARG, "device index out of range");
-  if ((e = hipSetDevice(device)) != hipSuccess) return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
+  DevGuard guard_(device);
+  if (!guard_.ok) return fail(nullptr, CSPM_ERR_HIP, "hipSetDevice failed");
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(nullptr, CSPM_ERR_HIP, std::string("libcspm_hip is built for gfx950 only, device is ") + prop.gcnArchName);
   cspm_ctx *c = new cspm_ctx();
   c->device = device;
+  c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
     return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
@@ -556,7 +669,7 @@ int cspm_create(cspm_ctx **out, int device) {
 
 void cspm_destroy(cspm_ctx *c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DevGuard guard_(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto &r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : c->pool) (void)hipEventDestroy(e);
@@ -571,6 +684,8 @@ const char *cspm_last_error(const cspm_ctx *c) { return c ? c->err.c_str() : g_c
 
 int cspm_set_stream(cspm_ctx *c, void *s) {
   if (!c) return CSPM_ERR_ARG;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return CSPM_OK;
@@ -578,16 +693,24 @@ int cspm_set_stream(cspm_ctx *c, void *s) {
 
 int cspm_synchronize(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  int rc = check_sweep(c);  // also surfaces a timed-out raster sweep of an asynchronous cspm_patchmatch
+  if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return CSPM_OK;
 }
 
+// The work is enqueued on the ctx stream.  Device sources: the caller orders its producer before this call on the same
+// stream (or synchronises); nothing here waits for the host.  Host sources: rows are gathered with a 2-D copy (a padded
+// row is never read past 3*w bytes) into a staging buffer the ctx keeps.
 static int set_images_impl(cspm_ctx *c, const void *l, const void *r, int w, int h, size_t stride, bool on_device) {
   if (!c) return CSPM_ERR_ARG;
   if (!l || !r || w < 1 || h < 1 || stride < (size_t)w * 3) return fail(c, CSPM_ERR_ARG, "bad image arguments");
-  HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   if (w != c->W || h != c->H) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     free_cost(c);
     free_field(c);
     free_images(c);
@@ -599,20 +722,28 @@ static int set_images_impl(cspm_ctx *c, const void *l, const void *r, int w, int
     c->cost_ready = false;
   }
   const void *src[2] = {l, r};
-  uint8_t *tmp = nullptr;
-  if (!on_device) HIPCHK(c, hipMalloc((void **)&tmp, stride * h));
+  const size_t row = (size_t)w * 3;
+  if (!on_device && c->stage_bytes < 2 * row * h) {
+    if (c->stage) (void)hipFree(c->stage);
+    c->stage = nullptr;
+    c->stage_bytes = 0;
+    HIPCHK(c, hipMalloc((void **)&c->stage, 2 * row * h));
+    c->stage_bytes = 2 * row * h;
+  }
   for (int v = 0; v < 2; ++v) {
     const uint8_t *d_src = (const uint8_t *)src[v];
+    size_t d_stride = stride;
     if (!on_device) {
-      HIPCHK(c, hipMemcpyAsync(tmp, src[v], stride * h, hipMemcpyHostToDevice, c->stream));
-      d_src = tmp;
+      uint8_t *dst = c->stage + (size_t)v * row * h;
+      HIPCHK(c, hipMemcpy2DAsync(dst, row, src[v], stride, row, h, hipMemcpyHostToDevice, c->stream));
+      d_src = dst;
+      d_stride = row;
     }
     Timed t(c, CSPM_K_MISC, 0);
-    hipLaunchKernelGGL(k_pack_bgr, dim3(ew_grid((long long)w * h)), dim3(256), 0, c->stream, d_src, stride, w, h, w, 0, c->img0[v]);
-    if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_pack_bgr, dim3(ew_grid((long long)w * h)), dim3(256), 0, c->stream, d_src, d_stride, w, h, w, 0, c->img0[v]);
   }
-  if (tmp) (void)hipFree(tmp);
   HIPCHK(c, hipGetLastError());
+  if (!on_device) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may reuse its host buffers
   return CSPM_OK;
 }
 
@@ -634,9 +765,10 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
 
 int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const bool with_vol = c->opt_grd_volumes != 0;
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol);
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindGrd);
   if (rc) return rc;
   Cost &cd = c->cost;
   // gradients of both views per level (grd_cc.cpp:70-77); then the GRD cells of both views
@@ -646,9 +778,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
     Level &L = cd.lv[s];
     const long long ppx = (long long)L.Wp * L.H;
     for (int v = 0; v < 2; ++v) {
-      double *g;
-      if ((rc = dalloc(c, &g, (size_t)ppx, &c->cost_allocs))) return rc;
-      L.grd[v] = g;
+      double *g = const_cast<double *>(L.grd[v]);
       Timed t(c, CSPM_K_GRD, 0);
       hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H,
                          L.Wp, L.pad, g);
@@ -665,51 +795,41 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   HIPCHK(c, hipGetLastError());
   cd.fused = with_vol ? kSrcVolume : kSrcGrd;
   c->is_grd = true;
-  return finish_cost(c);
+  return finish_cost(c, false);
 }
 
 // `new PreSSPC/PreCSPC(l, r, max_dis, wnd, [scale_num,] new CenCC, [reg_lambda])`: census volumes of every level
 // built on the device (cc/cen_cc.cc:4-137), then read by the PatchMatch kernels like any CCMethod's volumes.
 int cspm_build_cost_cen(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const bool with_vol = c->opt_grd_volumes != 0;
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol);
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindCen);
   if (rc) return rc;
   Cost &cd = c->cost;
-  std::vector<void *> tmp;
-  auto done = [&](int code) {
-    for (void *p : tmp) (void)hipFree(p);
-    return code;
-  };
   for (int s = 0; s < cd.levels; ++s) {
     Level &L = cd.lv[s];
     const long long px = (long long)L.W * L.H, ppx = (long long)L.Wp * L.H;
-    uint32_t *code[2];
     for (int v = 0; v < 2; ++v) {
-      uint8_t *gray;
-      PixC *pc;
-      if ((rc = dalloc(c, &gray, (size_t)px, &tmp)) || (rc = dalloc(c, &code[v], (size_t)px * 3, &c->cost_allocs)) ||
-          (rc = dalloc(c, &pc, (size_t)ppx, &c->cost_allocs)))
-        return done(rc);
-      L.pc[v] = pc;
-      c->cen_code[v][s] = code[v];
+      uint8_t *gray = c->cen_gray[v][s];
+      uint32_t *code = const_cast<uint32_t *>(c->cen_code[v][s]);
       Timed t(c, CSPM_K_GRD, 0);
       hipLaunchKernelGGL(k_gray8<SrcU32>, dim3(ew_grid(px)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H, gray);
-      hipLaunchKernelGGL(k_census, dim3(ew_grid(px)), dim3(256), 0, c->stream, gray, L.W, L.H, code[v]);
-      hipLaunchKernelGGL(k_make_aos_cen, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], code[v], L.W, L.H, L.Wp, L.pad, pc);
+      hipLaunchKernelGGL(k_census, dim3(ew_grid(px)), dim3(256), 0, c->stream, gray, L.W, L.H, code);
+      hipLaunchKernelGGL(k_make_aos_cen, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], code, L.W, L.H, L.Wp, L.pad, (PixC *)L.pc[v]);
       hipLaunchKernelGGL(k_make_aos, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)nullptr, ppx, (PixG *)L.px[v]);
     }
     for (int v = 0; v < 2; ++v) {  // volumes when asked for, their max (pre_cs_pc.cc:75-82) always
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid(px * (L.D + 1))), dim3(256), 0, c->stream, code[0], code[1], L.W, L.H, 0, L.D + 1, v,
-                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+      hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid(px * (L.D + 1))), dim3(256), 0, c->stream, c->cen_code[0][s], c->cen_code[1][s], L.W, L.H,
+                         0, L.D + 1, v, (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
     }
   }
   HIPCHK(c, hipGetLastError());
   cd.fused = with_vol ? kSrcVolume : kSrcCen;
   c->is_cen = true;
-  return done(finish_cost(c));
+  return finish_cost(c, false);
 }
 
 // CenCC::buildCV / buildRightCV on host buffers (cc_method.h:31-32, cc/cen_cc.cc:4-137)
@@ -747,8 +867,9 @@ int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
 
 int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
   if (!c) return CSPM_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, true);
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, true, kKindForeign);
   if (rc) return rc;
   for (int s = 0; s < c->cost.levels; ++s)
     for (int v = 0; v < 2; ++v) {
@@ -766,6 +887,8 @@ int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double 
   if (view < 0 || view > 1 || level < 0 || level >= c->cost.levels || !slab) return fail(c, CSPM_ERR_ARG, "bad view/level/slab");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D || stride_elems < (size_t)L.W) return fail(c, CSPM_ERR_ARG, "bad slab index or stride");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   double *dst = (double *)L.vol[view] + (size_t)d * L.W * L.H;
   HIPCHK(c, hipMemcpy2DAsync(dst, sizeof(double) * L.W, slab, sizeof(double) * stride_elems, sizeof(double) * L.W, L.H,
                              hipMemcpyHostToDevice, c->stream));
@@ -777,16 +900,21 @@ int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double 
 int cspm_finish_cost(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
   if (!c->cost_alloc || c->is_grd || c->is_cen || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_maxkeys + 2 * CSPM_MAX_LEVELS, 0xFF, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
   for (int s = 0; s < c->cost.levels; ++s)
     for (int v = 0; v < 2; ++v) {
       const Level &L = c->cost.lv[s];
       const long long cells = (long long)(L.D + 1) * L.W * L.H;
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_volume_max, dim3(2048), dim3(256), 0, c->stream, L.vol[v], cells, c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+      hipLaunchKernelGGL(k_volume_max, dim3(2048), dim3(256), 0, c->stream, L.vol[v], cells, c->d_maxkeys + v * CSPM_MAX_LEVELS + s,
+                         c->d_maxkeys + 2 * CSPM_MAX_LEVELS + v * CSPM_MAX_LEVELS + s);
     }
   HIPCHK(c, hipGetLastError());
-  return finish_cost(c);
+  c->max_cost_fetched = false;
+  return finish_cost(c, true);  // a foreign volume may hold negative cells: the early exit is licensed only when its min is >= 0
 }
 
 int cspm_get_levels(const cspm_ctx *c) { return (c && c->cost_alloc) ? c->cost.levels : 0; }
@@ -802,6 +930,8 @@ int cspm_get_level_dims(const cspm_ctx *c, int level, int *w, int *h, int *max_d
 int cspm_get_level_image(cspm_ctx *c, int view, int level, uint8_t *out) {
   if (!c || !out) return CSPM_ERR_ARG;
   if (!c->cost_alloc || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_ARG, "bad view/level");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const Level &L = c->cost.lv[level];
   const size_t px = (size_t)L.W * L.H;
   uint8_t *tmp;
@@ -818,6 +948,8 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
   if (!c->cost_alloc || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_ARG, "bad view/level");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D) return fail(c, CSPM_ERR_ARG, "bad slab index");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const size_t px = (size_t)L.W * L.H;
   if (L.vol[view]) {
     HIPCHK(c, hipMemcpyAsync(out, L.vol[view] + (size_t)d * px, sizeof(double) * px, hipMemcpyDeviceToHost, c->stream));
@@ -844,6 +976,10 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
 int cspm_get_max_cost(cspm_ctx *c, int view, int level, double *out) {
   if (!c || !out) return CSPM_ERR_ARG;
   if (!c->cost_ready || view < 0 || view > 1 || level < 0 || level >= c->cost.levels) return fail(c, CSPM_ERR_STATE, "cost not ready or bad view/level");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  int rc = fetch_max_cost(c);
+  if (rc) return rc;
   *out = c->host_max_cost[view * CSPM_MAX_LEVELS + level];
   return CSPM_OK;
 }
@@ -893,7 +1029,8 @@ int cspm_plane_cost_batch(cspm_ctx *c, int view, int n, const int *xy, const dou
   if (n == 0) return CSPM_OK;
   for (int i = 0; i < n; ++i)
     if (xy[2 * i] < 0 || xy[2 * i] >= c->W || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= c->H) return fail(c, CSPM_ERR_ARG, "pixel outside the image");
-  HIPCHK(c, hipSetDevice(c->device));
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   int *dxy = nullptr;
   double *dnp = nullptr, *dout = nullptr;
   std::vector<void *> tmp;
@@ -921,34 +1058,39 @@ int cspm_pm_default_params(cspm_pm_params *p) {
   return CSPM_OK;
 }
 
+#define PM_ENTER()                                                            \
+  if (!c) return CSPM_ERR_ARG;                                                \
+  DevGuard guard_(c->device);                                                 \
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");        \
+  int rc = check_pm(c, &p);                                                   \
+  if (rc) return rc
+
 int cspm_pm_init(cspm_ctx *c, const cspm_pm_params *p) {
-  int rc = check_pm(c, &p);
-  return rc ? rc : do_init(c, p);
+  PM_ENTER();
+  return do_init(c, p);
 }
 int cspm_pm_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
-  int rc = check_pm(c, &p);
-  if (rc) return rc;
+  PM_ENTER();
   if ((rc = do_spatial(c, iter, p))) return rc;
   return check_sweep(c);
 }
 int cspm_pm_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
-  int rc = check_pm(c, &p);
-  return rc ? rc : do_view(c, iter, p);
+  PM_ENTER();
+  return do_view(c, iter, p);
 }
 int cspm_pm_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
-  int rc = check_pm(c, &p);
-  return rc ? rc : do_refine(c, iter, p);
+  PM_ENTER();
+  return do_refine(c, iter, p);
 }
 
+// Asynchronous: everything is enqueued on the ctx stream and the call returns.  A raster sweep that timed out is
+// reported by the next synchronising call (cspm_synchronize or any getter).
 int cspm_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
-  int rc = check_pm(c, &p);
-  if (rc) return rc;
+  PM_ENTER();
   if (iter_num < 0 || iter_num > 15) return fail(c, CSPM_ERR_ARG, "iter_num out of range");
-  HIPCHK(c, hipSetDevice(c->device));
   if ((rc = do_init(c, p))) return rc;                 // cs_patchmatch.cc:55
   for (int i = 0; i < iter_num; ++i) {                 // :65-102
     if ((rc = do_spatial(c, i, p))) return rc;
-    if ((rc = check_sweep(c))) return rc;  // before the next sweep resets the control words
     if ((rc = do_view(c, i, p))) return rc;
     if ((rc = do_refine(c, i, p))) return rc;
   }
@@ -958,6 +1100,12 @@ int cspm_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
 int cspm_get_planes(cspm_ctx *c, int view, double *np_out, double *cost_out) {
   if (!c || view < 0 || view > 1) return CSPM_ERR_ARG;
   if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  {
+    int rc = check_sweep(c);
+    if (rc) return rc;
+  }
   const size_t n = (size_t)c->W * c->H;
   std::vector<double> h(7 * n);
   HIPCHK(c, hipMemcpyAsync(h.data(), c->f[view].nx, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, c->stream));
@@ -972,6 +1120,8 @@ int cspm_get_planes(cspm_ctx *c, int view, double *np_out, double *cost_out) {
 int cspm_set_planes(cspm_ctx *c, int view, const double *np, const double *cost) {
   if (!c || view < 0 || view > 1 || !np || !cost) return CSPM_ERR_ARG;
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images first");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   int rc = ensure_field(c);
   if (rc) return rc;
   const size_t n = (size_t)c->W * c->H;
@@ -987,6 +1137,8 @@ int cspm_set_planes(cspm_ctx *c, int view, const double *np, const double *cost)
 int cspm_disparity_u8_device(cspm_ctx *c, int view, int dis_scale, void *d_out) {
   if (!c || view < 0 || view > 1 || !d_out) return CSPM_ERR_ARG;
   if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   Pm pm{};
   pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
   {
@@ -1002,6 +1154,9 @@ int cspm_get_disparity_u8(cspm_ctx *c, int view, int dis_scale, uint8_t *out, si
   if (!c || !out || stride < (size_t)c->W) return CSPM_ERR_ARG;
   int rc = cspm_disparity_u8_device(c, view, dis_scale, c->d_dis[view < 0 || view > 1 ? 0 : view]);
   if (rc) return rc;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  if ((rc = check_sweep(c))) return rc;
   HIPCHK(c, hipMemcpy2DAsync(out, stride, c->d_dis[view], c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return CSPM_OK;
@@ -1010,6 +1165,12 @@ int cspm_get_disparity_u8(cspm_ctx *c, int view, int dis_scale, uint8_t *out, si
 int cspm_get_disparity_f64(cspm_ctx *c, int view, double *out) {
   if (!c || view < 0 || view > 1 || !out) return CSPM_ERR_ARG;
   if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  {
+    int rc = check_sweep(c);
+    if (rc) return rc;
+  }
   Pm pm{};
   pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
   const size_t n = (size_t)c->W * c->H;
@@ -1023,7 +1184,12 @@ int cspm_postprocess(cspm_ctx *c, int dis_scale, uint8_t *l_out, uint8_t *r_out,
   if (!c) return CSPM_ERR_ARG;
   if (!c->field_alloc || !c->cost_alloc) return fail(c, CSPM_ERR_STATE, "cspm_postprocess needs a finished PatchMatch");
   if (dis_scale < 1 || stride < (size_t)c->W || !l_out || !r_out) return fail(c, CSPM_ERR_ARG, "bad dis_scale / stride / outputs");
-  HIPCHK(c, hipSetDevice(c->device));
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  {
+    int rc = check_sweep(c);
+    if (rc) return rc;
+  }
   Pm pm{};
   pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
   const long long n = (long long)c->W * c->H;
@@ -1053,12 +1219,16 @@ int cspm_enable_timing(cspm_ctx *c, int on) {
 }
 int cspm_reset_timing(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   int rc = drain_timing(c);
   for (int k = 0; k < CSPM_K_COUNT; ++k) { c->acc_ms[k] = 0; c->acc_launch[k] = 0; c->acc_evals[k] = 0; }
   return rc;
 }
 int cspm_get_timing(cspm_ctx *c, int k, long long *launches, double *total_ms, long long *evals) {
   if (!c || k < 0 || k >= CSPM_K_COUNT) return CSPM_ERR_ARG;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   int rc = drain_timing(c);
   if (launches) *launches = c->acc_launch[k];
   if (total_ms) *total_ms = c->acc_ms[k];

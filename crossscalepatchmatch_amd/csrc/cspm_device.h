@@ -71,7 +71,7 @@ struct Cost {
   int groups;  // ceil(T/64)
   int rounds;  // ceil(groups/4): taps are processed 256 at a time
   const uint32_t *dec; // tap decode table, rounds*256 entries: dx | dy<<8, bit 31 set for t >= T
-  int early_ok;           // all scale weights and max_costs are >= 0
+  const int *early_ok;    // device flag: all scale weights, max_costs (and the cells of uploaded volumes) are >= 0
   const double *lut;      // lookup_exp_[i] = exp(-i/10), host-computed, kLutSize entries
   const double *lut_a;    // GRD colour term ALPHA*min(i*0.3333333333, TAU_CLR) (grd_cc.cpp:8-18), kLutSize entries
   const double *max_cost; // device, [view*CSPM_MAX_LEVELS + level]

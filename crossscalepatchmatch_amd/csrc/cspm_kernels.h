@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_refine(Cost cd, Pm pm, int iter,
   const double nx = d0 * inv, ny = d1 * inv, nz = d2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)y, pz, a, b, c);                // :330
-  const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, nx, ny, nz, a, b, c, cur_min, pm.use_thresh != 0, lane);
+  const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, nx, ny, nz, a, b, c, cur_min, (pm.use_thresh != 0 && *cd.early_ok != 0), lane);
   if (cost < cur_min && lane == 0) store_plane(f, i, nx, ny, nz, a, b, c, cost);  // :335-338
 }
 
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
     const long long j = (long long)nys[k] * pm.W + nxs[k];
     const Cand cand{f.nx[j], f.ny[j], f.nz[j], f.a[j], f.b[j], f.c[j]};
     const double cost = eval_plane<CS, SRC>(cd, lut, v, x, y, cand.nx, cand.ny, cand.nz, cand.a, cand.b, cand.c, best_cost,
-                                              pm.use_thresh != 0, lane);
+                                              (pm.use_thresh != 0 && *cd.early_ok != 0), lane);
     if (cost < best_cost) { best_cost = cost; best = cand; changed = true; }
   }
   if (changed && lane == 0) store_plane(f, i, best.nx, best.ny, best.nz, best.a, best.b, best.c, best_cost);
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_view_eval(Cost cd, Pm pm, int v,
   if (cor_x >= 0 && cor_x < pm.W) {
     plane_param(nx, ny, nz, (double)cor_x, (double)y, disp, a, b, c);     // :263-265
     const double thr = dst.cost[(long long)y * pm.W + cor_x];
-    cost = eval_plane<CS, SRC>(cd, lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, pm.use_thresh != 0, lane);  // :266-267
+    cost = eval_plane<CS, SRC>(cd, lut, v, cor_x, y, nx, ny, nz, a, b, c, thr, (pm.use_thresh != 0 && *cd.early_ok != 0), lane);  // :266-267
   }
   if (lane == 0) {
     vc.cost[i] = cost;
@@ -1215,26 +1215,44 @@ __global__ __launch_bounds__(256) void k_cen_volume(const uint32_t *__restrict__
   if (max_key && (threadIdx.x & 63) == 0) atomicMax(max_key, key);
 }
 
-// max over an uploaded (foreign CCMethod) volume
-__global__ __launch_bounds__(256) void k_volume_max(const double *__restrict__ vol, long long cells, unsigned long long *max_key) {
-  unsigned long long key = f64_key(-1.7976931348623157e308);
+// max and min over an uploaded (foreign CCMethod) volume
+__global__ __launch_bounds__(256) void k_volume_max(const double *__restrict__ vol, long long cells, unsigned long long *max_key,
+                                                    unsigned long long *min_key) {
+  unsigned long long key = f64_key(-1.7976931348623157e308), lo = f64_key(1.7976931348623157e308);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
     const unsigned long long k = f64_key(vol[i]);
     key = k > key ? k : key;
+    lo = k < lo ? k : lo;
   }
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
-    const unsigned long long other = __shfl_xor(key, off, kWave);
+    const unsigned long long other = __shfl_xor(key, off, kWave), olo = __shfl_xor(lo, off, kWave);
     key = other > key ? other : key;
+    lo = olo < lo ? olo : lo;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(max_key, key);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(max_key, key);
+    atomicMin(min_key, lo);
+  }
 }
-__global__ void k_keys_to_f64(const unsigned long long *keys, double *out, int n, double floor_val) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// keys -> max_cost[view][level] (the reference starts the max at -1.0, pre_cs_pc.cc:75) and the early-exit licence:
+// every scale weight (host-checked: wgt_ok), every max_cost and -- for uploaded volumes -- every cell minimum is >= 0
+__global__ void k_finish_cost(const unsigned long long *keys, double *out, int n, int levels, double floor_val, int wgt_ok, int check_min,
+                              int *early_ok) {
+  const int i = threadIdx.x;
+  int ok = 1;
   if (i < n) {
     const double v = key_f64(keys[i]);
-    out[i] = v > floor_val ? v : floor_val;  // the reference starts the max at -1.0 (pre_cs_pc.cc:75)
+    const double m = v > floor_val ? v : floor_val;
+    out[i] = m;
+    const int s = i % CSPM_MAX_LEVELS;
+    if (s < levels) {
+      if (!(m >= 0.0)) ok = 0;
+      if (check_min && !(key_f64(keys[n + i]) >= 0.0)) ok = 0;
+    }
   }
+  ok = __all(ok);
+  if (i == 0) *early_ok = (ok && wgt_ok) ? 1 : 0;
 }
 
 }  // namespace cspm

@@ -20,6 +20,8 @@ class CSPatchMatch {
   void set_schedule(int schedule, int rb_rounds = 1) { schedule_ = schedule; rb_rounds_ = rb_rounds; }
   // final plane field of a view, for callers that want sub-pixel disparities
   void planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const;
+  // unquantised disparity a*x+b*y+c of every pixel, row-major (what PlaneToDisp rounds, cs_patchmatch.cc:590-601)
+  void disparity(const RefView &view, std::vector<double> *out) const;
 
  private:
   Mat img_[kViewNum], dis_[kViewNum];

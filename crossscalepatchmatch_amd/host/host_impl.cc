@@ -54,14 +54,28 @@ void CenCC::buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat
 
 // ---------------------------------------------------------------- PreSSPC / PreCSPC
 int DevicePlaneCost::device = 0;
+bool DevicePlaneCost::keep_context = false;
+cspm_ctx *DevicePlaneCost::kept_ctx_ = NULL;
+int DevicePlaneCost::kept_device_ = -1;
+
+void DevicePlaneCost::release_kept_context() {
+  if (kept_ctx_) cspm_destroy(kept_ctx_);
+  kept_ctx_ = NULL;
+  kept_device_ = -1;
+}
 
 DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num,
                                  CCMethod *cc_method, double reg_lambda)
-    : ctx_(NULL) {
+    : ctx_(NULL), ctx_device_(device) {
   CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // pre_cs_pc.cc:25, pre_ss_pc.cc:24
   CV_Assert(l_img.rows == r_img.rows && l_img.cols == r_img.cols);
   if (!cc_method) throw std::runtime_error("PreSSPC/PreCSPC: NULL CCMethod (unknown --cc_name)");  // the reference dereferences it
-  check(cspm_create(&ctx_, device), NULL, "cspm_create");
+  if (kept_ctx_ && kept_device_ == device) {
+    ctx_ = kept_ctx_;
+    kept_ctx_ = NULL;
+  } else {
+    check(cspm_create(&ctx_, device), NULL, "cspm_create");
+  }
   const Mat l = l_img.clone(), r = r_img.clone();  // packed rows
   check(cspm_set_images(ctx_, l.data, r.data, l.cols, l.rows, l.step), ctx_, "cspm_set_images");
   if (dynamic_cast<GrdCC *>(cc_method)) {
@@ -103,7 +117,14 @@ void DevicePlaneCost::upload_foreign(CCMethod *cc, int view, int level) {
     check(cspm_upload_cost_slab(ctx_, view, level, d, vol[d].ptr<double>(0), vol[d].step / sizeof(double)), ctx_, "cspm_upload_cost_slab");
 }
 
-DevicePlaneCost::~DevicePlaneCost() { cspm_destroy(ctx_); }
+DevicePlaneCost::~DevicePlaneCost() {
+  if (keep_context && !kept_ctx_ && ctx_) {
+    kept_ctx_ = ctx_;
+    kept_device_ = ctx_device_;
+  } else {
+    cspm_destroy(ctx_);
+  }
+}
 
 double DevicePlaneCost::GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const {
   const int xy[2] = {ref_x, ref_y};
@@ -144,6 +165,12 @@ void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost,
       check(cspm_get_disparity_u8(ctx, v, dis_scale_, dis_[v].data, dis_[v].step), ctx, "cspm_get_disparity_u8");
   }
   last_ctx_ = ctx;
+}
+
+void CSPatchMatch::disparity(const RefView &view, std::vector<double> *out) const {
+  if (!last_ctx_) throw std::runtime_error("CSPatchMatch::disparity before PatchMatch");
+  out->resize((size_t)wid_ * hei_);
+  check(cspm_get_disparity_f64(last_ctx_, view, out->data()), last_ctx_, "cspm_get_disparity_f64");
 }
 
 void CSPatchMatch::planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const {

@@ -6,6 +6,10 @@
 #include "get_method.h"
 #include "plane_cost/pre_cs_pc.h"
 #include "plane_cost/pre_ss_pc.h"
+#include "pfm_io.h"
+
+#include <fstream>
+#include <sstream>
 
 // images
 DEFINE_string(l_img_file, "l_img.png", "left input image (8-bit PNG / PPM / PGM)");
@@ -24,20 +28,27 @@ DEFINE_int32(seed, 12345, "random seed (the reference uses the wall clock)");
 DEFINE_string(schedule, "raster", "spatial propagation: raster (the reference's sweep) | redblack");
 DEFINE_int32(device, 0, "GPU index");
 DEFINE_int32(iters, 3, "PatchMatch iterations (3 in the reference, main.cc:93)");
+DEFINE_string(l_disp_pfm, "", "also write the left sub-pixel disparity map as float32 PFM (unquantised a*x+b*y+c)");
+DEFINE_string(r_disp_pfm, "", "also write the right sub-pixel disparity map as float32 PFM");
+DEFINE_string(batch_list, "", "text file, one stereo pair per line: l_img r_img l_dis r_dis [l_pfm r_pfm]; all pairs run with the "
+                              "matching flags of this command line on one device context (buffers are reused between pairs)");
 
 namespace {
 const int kWindow = 35;  // main.cc:94
 const int kScales = 5;   // main.cc:100
 
-int run() {
-  const Mat left = imread(FLAGS_l_img_file, CV_LOAD_IMAGE_COLOR), right = imread(FLAGS_r_img_file, CV_LOAD_IMAGE_COLOR);
+struct PairFiles {
+  string l_img, r_img, l_dis, r_dis, l_pfm, r_pfm;
+};
+
+// one stereo pair: the flow of main.cc:57-139
+int run_pair(const PairFiles &f, CCMethod *cost_fn) {
+  const Mat left = imread(f.l_img, CV_LOAD_IMAGE_COLOR), right = imread(f.r_img, CV_LOAD_IMAGE_COLOR);
   if (left.empty() || right.empty()) {
     // the reference waits for a key press here (main.cc:70-75); a batch tool must not
     cout << "Error: can not open image\n";
     return EXIT_FAILURE;
   }
-  DevicePlaneCost::device = FLAGS_device;
-  CCMethod *cost_fn = GetCCType(FLAGS_cc_name);  // NULL for unknown names, rejected by the cost constructors
   const double t0 = static_cast<double>(getTickCount());
   IPlaneCost *plane_cost =
       FLAGS_use_cs ? static_cast<IPlaneCost *>(new PreCSPC(left, right, FLAGS_max_dis, kWindow, kScales, cost_fn, FLAGS_reg_lambda))
@@ -50,21 +61,67 @@ int run() {
   cout << "--------------------------------------------------------\n"
        << "Total Time: " << seconds << "\n"
        << "--------------------------------------------------------\n";
-  const bool written = imwrite(FLAGS_l_dis_file, matcher.dis(kLeft)) && imwrite(FLAGS_r_dis_file, matcher.dis(kRight));
+  bool written = imwrite(f.l_dis, matcher.dis(kLeft)) && imwrite(f.r_dis, matcher.dis(kRight));
+  const string *pfm[2] = {&f.l_pfm, &f.r_pfm};
+  for (int v = 0; v < kViewNum && written; ++v) {
+    if (pfm[v]->empty()) continue;
+    std::vector<double> d;
+    matcher.disparity(v == 0 ? kLeft : kRight, &d);
+    written = WritePFM(*pfm[v], d.data(), left.cols, left.rows);
+  }
   delete plane_cost;
-  delete cost_fn;
   if (!written) {
     cout << "Error: can not write disparity maps\n";
     return EXIT_FAILURE;
   }
   return EXIT_SUCCESS;
 }
+
+int run() {
+  DevicePlaneCost::device = FLAGS_device;
+  CCMethod *cost_fn = GetCCType(FLAGS_cc_name);  // NULL for unknown names, rejected by the cost constructors
+  int rc = EXIT_SUCCESS;
+  if (FLAGS_batch_list.empty()) {
+    cout << "Load Image: " << FLAGS_l_img_file << " " << FLAGS_r_img_file << "\n";
+    rc = run_pair(PairFiles{FLAGS_l_img_file, FLAGS_r_img_file, FLAGS_l_dis_file, FLAGS_r_dis_file, FLAGS_l_disp_pfm, FLAGS_r_disp_pfm}, cost_fn);
+  } else {
+    std::ifstream list(FLAGS_batch_list.c_str());
+    if (!list) {
+      cout << "Error: can not open batch list " << FLAGS_batch_list << "\n";
+      delete cost_fn;
+      return EXIT_FAILURE;
+    }
+    DevicePlaneCost::keep_context = true;  // the next pair's PreSSPC / PreCSPC takes over the device buffers of the last
+    const double t0 = static_cast<double>(getTickCount());
+    string line;
+    int pairs = 0;
+    while (rc == EXIT_SUCCESS && std::getline(list, line)) {
+      std::istringstream is(line);
+      PairFiles f;
+      if (!(is >> f.l_img)) continue;  // blank line
+      if (f.l_img[0] == '#') continue;
+      if (!(is >> f.r_img >> f.l_dis >> f.r_dis)) {
+        cout << "Error: batch list line needs l_img r_img l_dis r_dis: " << line << "\n";
+        rc = EXIT_FAILURE;
+        break;
+      }
+      is >> f.l_pfm >> f.r_pfm;
+      cout << "Load Image: " << f.l_img << " " << f.r_img << "\n";
+      rc = run_pair(f, cost_fn);
+      ++pairs;
+    }
+    const double seconds = (static_cast<double>(getTickCount()) - t0) / getTickFrequency();
+    cout << "Batch: " << pairs << " pairs in " << seconds << " s\n";
+    DevicePlaneCost::release_kept_context();
+  }
+  delete cost_fn;
+  return rc;
+}
 }  // namespace
 
 int main(int argc, char **argv) {
   cout << "PatchMatch Stereo Matching (MI355X)" << endl;
   gflags::ParseCommandLineFlags(&argc, &argv, true);
-  cout << "Load Image: " << FLAGS_l_img_file << " " << FLAGS_r_img_file << "\n";
   try {
     return run();
   } catch (const std::exception &e) {

@@ -12,9 +12,16 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
   virtual double GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const;
   virtual cspm_ctx *device_ctx() const { return ctx_; }
   static int device;  // GPU used by objects constructed from now on (the CLI's --device)
+  // batch mode: a destroyed object parks its cspm_ctx (device buffers included) for the next object on the same GPU,
+  // so a stream of equally sized pairs allocates once
+  static bool keep_context;
+  static void release_kept_context();
 
  private:
   DevicePlaneCost(const DevicePlaneCost &);
   void upload_foreign(CCMethod *cc, int view, int level);
   cspm_ctx *ctx_;
+  int ctx_device_;
+  static cspm_ctx *kept_ctx_;
+  static int kept_device_;
 };

@@ -88,6 +88,26 @@ int csor_scale_weights(int S, double lambda, double *w) {
       A[s * S + s + 1] = -lambda;
     }
   }
+  /* cv::invert(DECOMP_LU) of OpenCV 2.4 (lapack.cpp) does not run LU for n <= 3: it uses det2 / det3 and the
+   * cofactors times 1/det.  Restated from memory of those sources (not verifiable here); row 0 only. */
+  if (S == 1) { w[0] = 1. / A[0]; return 0; }
+  if (S == 2) {
+    double d = A[0] * A[3] - A[1] * A[2];
+    if (d == 0.) return -2;
+    d = 1. / d;
+    w[0] = A[3] * d;
+    w[1] = -A[1] * d;
+    return 0;
+  }
+  if (S == 3) {
+    double d = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (d == 0.) return -2;
+    d = 1. / d;
+    w[0] = (A[4] * A[8] - A[5] * A[7]) * d;
+    w[1] = (A[2] * A[7] - A[1] * A[8]) * d;
+    w[2] = (A[1] * A[5] - A[2] * A[4]) * d;
+    return 0;
+  }
   const double eps = DBL_EPSILON * 100;
   for (int i = 0; i < S; ++i) {
     int k = i;

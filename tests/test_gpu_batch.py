@@ -1,0 +1,60 @@
+"""batch.run_batch with the real per-pair function (HipPairFn -> libcspm_hip.so) on a device: world 1 in-process, and two
+ranks sharing GPU 0 with a gloo control plane (the only way to run world > 1 on a 1-GPU box).  Every map must equal the
+direct C-ABI path on the same pair and seed."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from crossscalepatchmatch_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, D = 72, 40, 12
+PARAMS = dict(w=W, h=H, max_dis=D, dis_scale=4, scale_num=3, reg_lambda=0.3, iters=2, seed=500, schedule=0, use_pp=0)
+
+
+def _pairs(n):
+    return np.stack([np.stack(synth.make_pair(W, H, D, 3, 40 + i)[:2]) for i in range(n)])
+
+
+def _direct(ctx, pairs, use_pp=0):
+    out = []
+    for i, (l, r) in enumerate(pairs):
+        ctx.set_images(l, r)
+        ctx.build_cost_grd(D, 35, PARAMS["scale_num"], PARAMS["reg_lambda"])
+        ctx.patchmatch(PARAMS["iters"], seed=PARAMS["seed"] + i, schedule=0)
+        out.append(ctx.postprocess(4) if use_pp else (ctx.disparity_u8(0, 4), ctx.disparity_u8(1, 4)))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("use_pp", [0, 1])
+def test_run_batch_world1_on_device(gpu_ctx, use_pp):
+    import torch
+    from crossscalepatchmatch_amd import batch
+    pairs = _pairs(3)
+    fn = batch.HipPairFn(0)
+    got = batch.run_batch(pairs, dict(PARAMS, use_pp=use_pp), fn, device="cuda:0", dist=None)
+    fn.ctx.synchronize()
+    torch.cuda.synchronize()
+    fn.close()
+    np.testing.assert_array_equal(got.cpu().numpy(), _direct(gpu_ctx, pairs, use_pp))
+
+
+def test_run_batch_two_ranks_one_gpu(gpu_ctx, tmp_path):
+    """2 processes, gloo rendezvous on 127.0.0.1, both computing on cuda:0 with HipPairFn; 5 pairs -> blocks of 3 and 2."""
+    pairs = _pairs(5)
+    np.save(tmp_path / "pairs.npy", pairs)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "batch_rank.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=600)
+    got = np.load(tmp_path / "out.npy")
+    np.testing.assert_array_equal(got, _direct(gpu_ctx, pairs))

@@ -113,6 +113,66 @@ def test_foreign_cost_volume_upload(gpu_ctx, small_pair):
     np.testing.assert_array_equal(got, want)
 
 
+def test_foreign_volume_with_negative_cells_disables_the_early_exit(gpu_ctx, small_pair):
+    """A plugin cost may be negative (NCC-style) while its max is >= 0: partial sums are then not monotone and the early
+    exit would reject planes the reference accepts.  cspm_finish_cost reduces the MIN of the uploaded volumes too and
+    withdraws the early-exit licence: the whole PatchMatch (early_exit=1, the default) still equals the oracle."""
+    pc = po.PlaneCost(small_pair["l"], small_pair["r"], small_pair["max_dis"], 35, 3, 0.3)
+    rng = np.random.default_rng(8)
+    gpu_ctx.set_images(small_pair["l"], small_pair["r"])
+    gpu_ctx.begin_cost(small_pair["max_dis"], 35, 3, 0.3)
+    for s in range(pc.levels):
+        for v in (0, 1):
+            vol = pc.volume(v, s)
+            vol[...] = rng.uniform(-4.0, 1.0, vol.shape)  # mostly negative cells, positive max
+            for d in range(vol.shape[0]):
+                gpu_ctx.upload_cost_slab(v, s, d, vol[d])
+    pc.refresh_max_cost()
+    gpu_ctx.finish_cost()
+    assert gpu_ctx.max_cost(0, 0) == pc.max_cost(0, 0) > 0
+    pm = po.PatchMatch(small_pair["l"], small_pair["r"], small_pair["max_dis"], 4)
+    pm.run(2, pc, False, seed=6, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.patchmatch(2, seed=6, schedule=0, early_exit=1)
+    for v in (0, 1):
+        npar, cost = gpu_ctx.get_planes(v)
+        np.testing.assert_array_equal(cost, pm.min_cost(v))
+        np.testing.assert_array_equal(npar[..., :3], pm.planes(v)[..., 0:3])
+
+
+def test_padded_host_rows_and_rois(gpu_ctx, small_pair):
+    """cspm_set_images takes a row stride (a cv::Mat ROI): only 3*w bytes of each row are read, the last row included --
+    the buffer below ENDS right after the last pixel of the last row."""
+    import ctypes as C
+    import crossscalepatchmatch_amd as cs
+    L = cs.load_library()
+    h, w = small_pair["h"], small_pair["w"]
+    stride = 3 * w + 37
+    bufs = []
+    for img in (small_pair["l"], small_pair["r"]):
+        b = np.full(stride * (h - 1) + 3 * w, 0xAB, np.uint8)
+        for y in range(h):
+            b[y * stride:y * stride + 3 * w] = img[y].reshape(-1)
+        bufs.append(b)
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    assert L.cspm_set_images(gpu_ctx.p, u8(bufs[0]), u8(bufs[1]), w, h, stride) == 0
+    gpu_ctx.w, gpu_ctx.h = w, h
+    gpu_ctx.build_cost_grd(small_pair["max_dis"], 35, 2, 0.3)
+    for v, img in ((0, small_pair["l"]), (1, small_pair["r"])):
+        np.testing.assert_array_equal(gpu_ctx.level_image(v, 0), img)
+
+
+def test_scale_weights_small_level_counts(gpu_ctx, small_pair):
+    """scale_num 1..3 take cv::invert's closed-form path (det2 / det3), 4.. the LU path; device == oracle for all."""
+    gpu_ctx.set_images(small_pair["l"], small_pair["r"])
+    for sn in (1, 2, 3, 4, 5):
+        for lam in (0.0, 0.3, 1.0):
+            gpu_ctx.build_cost_grd(small_pair["max_dis"], 35, sn, lam)
+            o = np.zeros(8)
+            assert po.lib().csor_scale_weights(sn, lam, o.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))) == 0
+            np.testing.assert_array_equal(gpu_ctx.scale_weights(), o[:sn])
+            assert abs(gpu_ctx.scale_weights().sum() - 1.0) < 1e-12  # rows of inv(M) sum to 1: M has unit row sums
+
+
 def test_errors(gpu_ctx, small_pair):
     import crossscalepatchmatch_amd as cs
     gpu_ctx.set_images(small_pair["l"], small_pair["r"])

@@ -116,6 +116,30 @@ def test_c1_single_scale_config(gpu_ctx):
     assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.25
 
 
+def test_c2_whole_pipeline_bit_exact(gpu_ctx):
+    """BASELINE.json configs[1]: teddy-size 450x375, max_dis=60, GRD, use_cs=true (5 levels, lambda 0.3) -- the WHOLE
+    pipeline (init + 3 x (raster sweep, view propagation, refinement) + PlaneToDisp) through the C ABI, every plane, cost
+    and disparity compared with the oracle (device summation order).  ~5.9e10 window taps on the host: a minute or two."""
+    cfg, l, r, gl, gr = synth.make_config("C2")
+    assert (cfg["w"], cfg["h"], cfg["max_dis"], cfg["scale_num"]) == (450, 375, 60, 5)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    assert [gpu_ctx.level_dims(s) for s in range(5)] == [(450, 375, 60), (225, 188, 30), (113, 94, 15), (57, 47, 7), (29, 24, 3)]
+    gpu_ctx.patchmatch(3, seed=12345, schedule=0)
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
+    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    for v in (0, 1):
+        npar, cost = gpu_ctx.get_planes(v)
+        P = pm.planes(v)
+        np.testing.assert_array_equal(npar[..., :3], P[..., 0:3])
+        np.testing.assert_array_equal(npar[..., 3:], P[..., 6:9])
+        np.testing.assert_array_equal(cost, pm.min_cost(v))
+        np.testing.assert_array_equal(gpu_ctx.disparity_u8(v, cfg["dis_scale"]), pm.dis(v))
+        np.testing.assert_array_equal(gpu_ctx.disparity_f64(v), pm.disp_f64(v))
+    assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.2
+
+
 def test_c5_full_resolution_runs(gpu_ctx):
     """BASELINE.json configs[4]: 3000x2000, max_dis=256, cross-scale, use_pp=true.  f64 volumes would be 28 GB; the
     fused cost needs ~0.3 GB.  One iteration + post-processing; self-consistency of stored costs."""
