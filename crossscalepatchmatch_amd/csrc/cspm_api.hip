@@ -77,6 +77,7 @@ struct cspm_ctx {
   unsigned long long *d_maxkeys = nullptr;
   // plane field
   bool field_alloc = false;
+  bool field_consistent = false;  // every min_cost was computed from the stored plane by this cost object (not by cspm_set_planes)
   double *field_mem = nullptr;
   Field f[2]{};
   ViewCand vc{nullptr, nullptr, nullptr};
@@ -166,6 +167,16 @@ int drain_timing(cspm_ctx *c) {
   c->recs.clear();
   return CSPM_OK;
 }
+
+// row engine: one wave per 64-pixel run of an image row, kRowWaves waves per workgroup, grid a multiple of 8 (XCD bands)
+inline unsigned row_grid(int W, int H, int views) {
+  const long long items = (long long)views * H * ((W + kWave - 1) / kWave);
+  long long nb = (items + kRowWaves - 1) / kRowWaves;
+  nb = (nb + 7) / 8 * 8;
+  return (unsigned)nb;
+}
+inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
+inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * row_cap(c) * 16; }
 
 inline unsigned eval_grid(long long items) {
   long long nb = (items + (kEvalBlock / kWave) - 1) / (kEvalBlock / kWave);
@@ -303,7 +314,7 @@ void launch_pyramid(cspm_ctx *c) {
 // image size, max_dis, window, levels, kind, volumes) reuses every buffer: no allocator call, no host synchronisation.
 int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind) {
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
-  if (max_dis < 1 || wnd_size < 1 || wnd_size > 45 || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
+  if (max_dis < 1 || wnd_size < 1 || wnd_size > kMaxWnd || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
     return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
   CostKey key;
   key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
@@ -319,9 +330,6 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     cd.half = wnd_size / 2;
     cd.n = 2 * cd.half + 1;
     cd.T = cd.n * cd.n;
-    cd.groups = (cd.T + kWave - 1) / kWave;
-    cd.rounds = (cd.groups + 3) / 4;
-    if (cd.rounds > kMaxRounds) return fail(c, CSPM_ERR_ARG, "wnd_size too large (the tap decode table holds 2048 taps: wnd_size <= 45)");
     c->max_dis = max_dis;
     c->wnd = wnd_size;
     // pre_cs_pc.cc:36-55
@@ -330,7 +338,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
       if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
       Level &L = cd.lv[s];
       L.W = W; L.H = H; L.D = D;
-      L.pad = D + 2;
+      L.pad = D + cd.half + 8;  // cspm_device.h: window overrun and disparity range stay inside the padding
       L.Wp = W + 2 * L.pad;
       if ((long long)L.Wp * H * 12 >= (1LL << 31) || L.Wp * 12 >= (1 << 23))
         return fail(c, CSPM_ERR_ARG, "image too large for the 32-bit / 24-bit element offsets of the tap engine");
@@ -347,7 +355,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         L.vol[v] = nullptr;
         if (with_vol) {
           double *vol;
-          if ((rc = dalloc(c, &vol, (size_t)(D + 1) * px, &c->cost_allocs))) return rc;
+          if ((rc = dalloc(c, &vol, (size_t)(D + 2) * px, &c->cost_allocs))) return rc;  // D+1 slabs and one guard slab (clamped taps of a level with D < 2)
           L.vol[v] = vol;
         }
         if (kind == kKindGrd) {
@@ -379,14 +387,6 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     c->d_lut_a = c->d_lut + kLutSize;
     if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
     if ((rc = dalloc(c, &c->d_early_ok, 1, &c->cost_allocs))) return rc;
-    {  // tap decode table: t -> (dx, dy) of the linearised window, bit 31 marks the padding taps t >= T
-      std::vector<uint32_t> dec((size_t)cd.rounds * 256);
-      for (int t = 0; t < cd.rounds * 256; ++t) dec[t] = t < cd.T ? (uint32_t)((t % cd.n) | ((t / cd.n) << 8)) : 0x80000000u;
-      uint32_t *d_dec;
-      if ((rc = dalloc(c, &d_dec, dec.size(), &c->cost_allocs))) return rc;
-      HIPCHK(c, hipMemcpy(d_dec, dec.data(), dec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      cd.dec = d_dec;
-    }
     if ((rc = dalloc(c, &c->d_maxkeys, 4 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
     HIPCHK(c, hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     cd.lut = c->d_lut;
@@ -477,6 +477,7 @@ Pm make_pm(cspm_ctx *c, const cspm_pm_params *p) {
   pm.W = c->W; pm.H = c->H; pm.max_dis = c->max_dis;
   pm.seed = p->seed;
   pm.rng_row_shared = p->rng_mode == CSPM_RNG_ROW_SHARED;
+  pm.trust_cost = c->field_consistent ? 1 : 0;
   pm.use_thresh = p->early_exit ? 1 : 0;  // and-ed with the cost object's device-side licence (Cost::early_ok) in the kernels
   pm.f[0] = c->f[0];
   pm.f[1] = c->f[1];
@@ -530,10 +531,16 @@ int do_init(cspm_ctx *c, const cspm_pm_params *p) {
   Pm pm = make_pm(c, p);
   {
     Timed t(c, CSPM_K_INIT, items);
-    LAUNCH_CS(k_init, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm);
+    LAUNCH_CS(k_init, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, row_cap(c));
   }
   HIPCHK(c, hipGetLastError());
+  c->field_consistent = true;
   return CSPM_OK;
+}
+
+// waves of a sweep workgroup: cross-scale -> one per pyramid level; single-scale -> one per chain pass of a full window
+inline unsigned sweep_waves(const cspm_ctx *c) {
+  return c->cost.cs ? (unsigned)c->cost.levels : (unsigned)((c->cost.n + kChainRows - 1) / kChainRows);
 }
 
 int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
@@ -575,7 +582,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, sizeof(unsigned int), c->stream));  // the claim counter; ctrl[1] is sticky
     int ncu = c->ncu;
     const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * 6);  // more than fit is harmless: unclaimed work is all a late workgroup needs
-    const unsigned waves = c->cost.cs ? (unsigned)c->cost.levels : 4u;  // one wave per level, or per accumulator block
+    const unsigned waves = sweep_waves(c);
     {
       Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
       LAUNCH_CS(k_spatial_sweep, dim3(grid), dim3(waves * kWave), 0, c->cost, pm, sw, inc);
@@ -586,7 +593,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
       const long long items = 2LL * (ys_hi - ys_lo + 1);
       Timed t(c, CSPM_K_SPATIAL, items * 2);
-      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(kDiagBlock), 0, c->cost, pm, k, inc);
+      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), 0, c->cost, pm, k, inc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -601,7 +608,7 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   for (int v = 0; v < 2; ++v) {
     {
       Timed t(c, CSPM_K_VIEW, items);
-      LAUNCH_CS(k_view_eval, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, v, c->vc);
+      LAUNCH_CS(k_view_eval, dim3(row_grid(c->W, c->H, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, v, c->vc, row_cap(c));
     }
     {
       Timed t(c, CSPM_K_MISC, 0);
@@ -615,16 +622,13 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
 int do_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   Pm pm = make_pm(c, p);
   const long long items = 2LL * c->W * c->H;
-  double z_iter = c->max_dis / 2.0, n_iter = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145
-  int step = 0;
-  while (z_iter >= 0.1) {                          // kZStopThres_, cs_patchmatch.h:146
-    {
-      Timed t(c, CSPM_K_REFINE, items);
-      LAUNCH_CS(k_refine, dim3(eval_grid(items)), dim3(kEvalBlock), 0, c->cost, pm, iter, step, z_iter, n_iter);
-    }
-    z_iter /= 2.0;
-    n_iter /= 2.0;
-    ++step;
+  const double z_iter = c->max_dis / 2.0, n_iter = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145
+  int steps = 0;
+  for (double z = z_iter; z >= 0.1; z /= 2.0) ++steps;   // kZStopThres_, cs_patchmatch.h:146
+  if (steps > 0) {
+    // all halving steps of the iteration in ONE launch: a pixel's steps depend only on its own earlier steps
+    Timed t(c, CSPM_K_REFINE, items * steps);
+    LAUNCH_CS(k_refine, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, iter, 0, steps, z_iter, n_iter, row_cap(c));
   }
   HIPCHK(c, hipGetLastError());
   return CSPM_OK;
@@ -1131,6 +1135,7 @@ int cspm_set_planes(cspm_ctx *c, int view, const double *np, const double *cost)
   memcpy(h.data() + 6 * n, cost, sizeof(double) * n);
   HIPCHK(c, hipMemcpyAsync(c->f[view].nx, h.data(), sizeof(double) * 7 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->field_consistent = false;  // min_cost is whatever the caller says: the sweep may not assume cost(plane) == min_cost
   return CSPM_OK;
 }
 

@@ -1,0 +1,535 @@
+// cspm_chain.h -- the CHAIN ENGINE: one wavefront evaluates one or two candidate planes at ONE pixel; the support window
+// is spread over the lanes.  It serves the code paths whose pixel order is inherently serial -- the raster sweep of
+// CSPatchMatch::SpatialPropagation (cs_patchmatch.cc:163-216), where a pixel needs the final planes of its two
+// predecessors -- and single evaluations (cspm_plane_cost_batch, the red-black option).
+//
+// Lane <-> tap mapping.  Window row dy has kRowMod = 7 interleaved chains (taps dx = j, j+7, j+14, ...: the partial sums
+// S[j] of the ROWTREE7 order, cspm_tap.h).  A pass gives 9 rows x 7 chains to lanes 0..62 (lane 63 idles); only rows
+// inside the image get lanes (levels 3-4 of a KITTI pyramid are shorter than the window: no masked rows), so a 35x35
+// window takes ceil(rows/9) <= 4 passes of 5 taps per lane.  A lane's own-view addresses advance by a constant 7
+// elements, the lanes of a row read 7 consecutive elements: row runs, like the window itself.
+// Per pass and candidate the plane enters through two per-wave LDS tables
+//   tabx[dx] = plane_a * q_x            (the product of pre_cs_pc.cc:165)
+//   taby[dy] = plane_b * q_y + plane_c  (q_disp_y, pre_cs_pc.cc:155)
+// so a tap's q_disp is one add -- each entry is rounded exactly like the expression it replaces.
+// After the passes the chain sums go through LDS once: lane dy adds the 7 partial sums of row dy, and an xor butterfly
+// over the lanes forms the row tree.
+#pragma once
+#include "cspm_tap.h"
+
+#pragma clang fp contract(off)
+
+namespace cspm {
+
+// per-wave LDS scratch of the chain engine
+struct ChainScratch {
+  double tab[2][2][kWave];            // [candidate][x | y][entry]; taps past the window edge read (and discard) stale entries
+  double part[kMaxPasses * kWave];    // chain sums of one candidate, pass-major
+};
+
+// everything one level needs, wave-uniform
+struct ChainLevel {
+  int W, H, n, Dm1;
+  int ox0, oy0;        // image coordinates of window tap (0,0)
+  int r_lo, nrows;     // first window row inside the image, number of rows inside
+  int passes, nsteps;  // ceil(nrows / 9), ceil(n / 7)
+  int Wp, pad;
+  bool has_valid;
+  double maxc;
+  const char *px, *opx;  // own / other view elements
+  int dirE;              // byte step towards larger disparity in the other view: -E (left view) or +E
+  const double *vol;
+  size_t slab;
+  uint32_t Ip;
+};
+
+template <int SRC>
+__device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, int view, int cx, int cy) {
+  const Level &L = cd.lv[s];
+  constexpr int E = elem_size<SRC>();
+  ChainLevel A;
+  A.W = L.W; A.H = L.H; A.n = cd.n; A.Dm1 = L.D - 1;
+  A.ox0 = cx - cd.half; A.oy0 = cy - cd.half;
+  A.r_lo = max(0, -A.oy0);
+  const int r_hi = min(cd.n - 1, L.H - 1 - A.oy0);
+  A.nrows = r_hi - A.r_lo + 1;
+  A.passes = (A.nrows + kChainRows - 1) / kChainRows;
+  A.nsteps = (cd.n + kRowMod - 1) / kRowMod;
+  A.Wp = L.Wp; A.pad = L.pad;
+  A.has_valid = L.D >= 2;
+  A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
+  if (SRC == kSrcCen) {
+    A.px = reinterpret_cast<const char *>(L.pc[view]); A.opx = reinterpret_cast<const char *>(L.pc[1 - view]);
+    A.Ip = L.pc[view][cy * L.Wp + L.pad + cx].pix;
+  } else {
+    A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
+    A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
+  }
+  A.dirE = view == 0 ? -E : E;  // left view looks at x-d in the right image, right view at x+d in the left
+  A.vol = L.vol[view];
+  A.slab = (size_t)L.W * (size_t)L.H;
+  return A;
+}
+
+// fill candidate c's tables for this level (all lanes of the wave)
+__device__ __forceinline__ void fill_tabs(ChainScratch &m, int c, const ChainLevel &A, double pa, double pb, double pc, int lane) {
+  if (lane < A.n) {
+    m.tab[c][0][lane] = pa * (double)(A.ox0 + lane);
+    m.tab[c][1][lane] = pb * (double)(A.oy0 + lane) + pc;
+  }
+}
+
+// One level, NC candidates (1 or 2) at the same pixel: the plane-independent half of every tap (own element, guide
+// weight) is computed once.  `pass_first/pass_step` let several waves share the passes of one level (single-scale sweep).
+// Chain sums are left in S[c][pass slot]; finish_level() turns them into the level sum.
+template <int SRC, int NC>
+__device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainScratch &m, int lane,
+                                             int pass_first, int pass_step, double S[NC][kMaxPasses]) {
+  constexpr int E = elem_size<SRC>();
+  const int lutzero = kLutZero;
+  const int lr = lane / kRowMod, j = lane - lr * kRowMod;  // lane 63: lr = 9 -> never a valid chain
+#pragma unroll
+  for (int ps = 0; ps < kMaxPasses; ++ps) {
+    const int p = pass_first + ps * pass_step;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) S[c][ps] = 0.0;
+    if (p >= A.passes) continue;  // wave-uniform
+    const int r = p * kChainRows + lr;
+    const bool chain_ok = (lr < kChainRows) & (r < A.nrows);
+    const int dy = A.r_lo + (chain_ok ? r : 0);  // window row; idle lanes shadow row r_lo with zero weight
+    const int qx0 = A.ox0 + j;
+    const int ob = ((A.oy0 + dy) * A.Wp + A.pad + qx0) * E;  // byte offset of the chain's first tap
+    double ty[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ty[c] = m.tab[c][1][dy];
+    for (int st = 0; st < A.nsteps; ++st) {
+      const int dx = j + kRowMod * st;
+      const bool ok = chain_ok & (dx < A.n) & ((unsigned)(qx0 + kRowMod * st) < (unsigned)A.W);
+      const uint4 P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
+      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, pix_of<SRC>(P), 0u);
+      const int sad = ok ? sad0 : lutzero;  // masked taps get weight entry kLutZero = 0.0: they add +0.0
+      const double wgt = lut.w[sad];        // :161-164
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const double q_disp = m.tab[c][0][dx] + ty[c];  // :155,165
+        const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
+        double c0, c1;
+        if (SRC == kSrcVolume) {
+          const int qy = A.oy0 + dy, qx = ok ? qx0 + kRowMod * st : A.ox0 + cd.half;
+          const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
+          c0 = v[0];
+          c1 = v[A.slab];
+        } else {
+          const int of = ob + st * (kRowMod * E) + __mul24(A.dirE, d.f);
+          c0 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of));
+          c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of + A.dirE));
+        }
+        S[c][ps] += tap_value(d, c0, c1, A.maxc, wgt);
+      }
+    }
+  }
+}
+
+// chain sums of ONE candidate (already stored pass-major in part[]) -> level sum, identical in all lanes:
+// lane dy adds the 7 partial sums of window row dy left to right, the butterfly builds the row tree
+__device__ __forceinline__ double finish_level(const ChainLevel &A, const double *part, int lane) {
+  const int r = lane - A.r_lo;
+  const bool in = (r >= 0) & (r < A.nrows);
+  const int rc = in ? r : 0;
+  const int p = rc / kChainRows, lr = rc - p * kChainRows;
+  const double *q = part + p * kWave + lr * kRowMod;
+  double R = q[0];
+#pragma unroll
+  for (int k = 1; k < kRowMod; ++k) R = R + q[k];
+  R = in ? R : 0.0;
+  return wave_tree_sum(R);
+}
+
+// store the chain sums of candidate c (this wave's pass slots) into part[]
+template <int NC>
+__device__ __forceinline__ void store_parts(double *part, const double S[NC][kMaxPasses], int c, int lane, int pass_first, int pass_step,
+                                            int passes) {
+#pragma unroll
+  for (int ps = 0; ps < kMaxPasses; ++ps) {
+    const int p = pass_first + ps * pass_step;
+    if (p < passes) part[p * kWave + lane] = S[c][ps];
+  }
+}
+
+// Aggregated plane cost at (x,y) by ONE wave; +inf when the candidate is proven not to beat `thresh` (checked at
+// level ends with the exact partial total: all terms are >= 0 when Cost::early_ok).
+// (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param().
+template <bool CS, int SRC>
+__device__ __forceinline__ double eval_plane_chain(const Cost &cd, const Luts &lut, ChainScratch &m, int view, int x, int y, double nx,
+                                                   double ny, double nz, double pa, double pb, double pc, double thresh,
+                                                   bool use_thresh, int lane) {
+  double cost = 0.0;
+  double cur_disp = pa * (double)x + pb * (double)y + pc;  // pre_cs_pc.cc:139-140
+  int cur_x = x, cur_y = y;
+  const int levels = CS ? cd.levels : 1;
+  for (int s = 0; s < levels; ++s) {
+    double a = pa, b = pb, c = pc;
+    if (CS) plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
+    const ChainLevel A = make_chain_level<SRC>(cd, s, view, cur_x, cur_y);
+    wave_lds_fence();  // earlier reads of the tables / part[] are done
+    fill_tabs(m, 0, A, a, b, c, lane);
+    wave_lds_fence();
+    double S[1][kMaxPasses];
+    chain_passes<SRC, 1>(cd, A, lut, m, lane, 0, 1, S);
+    store_parts<1>(m.part, S, 0, lane, 0, 1, A.passes);
+    wave_lds_fence();
+    const double sc = finish_level(A, m.part, lane);
+    if (CS) cost += sc * cd.lv[s].wgt;  // :182
+    else cost = sc;
+    if (use_thresh && cost >= thresh) return __builtin_inf();
+    cur_y /= 2;  // :183-185
+    cur_x /= 2;
+    cur_disp /= 2.0;
+  }
+  return cost;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cspm_plane_cost_batch: batched GetPlaneCost on explicit (x,y,plane) tuples -- the parity hook.
+// ------------------------------------------------------------------------------------------------
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kEvalBlock) void k_cost_batch(Cost cd, int view, int n, const int *__restrict__ xy,
+                                                           const double *__restrict__ np, double *__restrict__ out) {
+  __shared__ LutMem s_lut;
+  __shared__ ChainScratch s_m[kEvalBlock / kWave];
+  const Luts lut = load_luts(cd, s_lut);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long e = xcd_block() * (kEvalBlock / kWave) + wave;
+  if (e >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int x = xy[2 * e], y = xy[2 * e + 1];
+  const double *p = np + 6 * e;
+  const double c = eval_plane_chain<CS, SRC>(cd, lut, s_m[wave], view, x, y, p[0], p[1], p[2], p[3], p[4], p[5], kDoubleMax, false, lane);
+  if (lane == 0) out[e] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSPatchMatch::SpatialPropagation, red-black half-step (optional lower-quality schedule).
+// ------------------------------------------------------------------------------------------------
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int colour, int inc, int nb) {
+  __shared__ LutMem s_lut;
+  __shared__ ChainScratch s_m[kEvalBlock / kWave];
+  const Luts lut = load_luts(cd, s_lut);
+  const int halfW = (pm.W + 1) / 2;
+  const long long per_view = (long long)halfW * pm.H;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long e = xcd_block() * (kEvalBlock / kWave) + wave;
+  if (e >= 2 * per_view) return;
+  const int lane = threadIdx.x & 63;
+  const int v = (int)(e / per_view);
+  const long long r = e - (long long)v * per_view;
+  const int y = (int)(r / halfW);
+  const int x = 2 * (int)(r - (long long)y * halfW) + ((y + colour) & 1);
+  if (x >= pm.W) return;
+  const Field &f = pm.f[v];
+  const long long i = (long long)y * pm.W + x;
+  Cand best{};
+  double best_cost = f.cost[i];
+  bool changed = false;
+  const bool use_thresh = pm.use_thresh != 0 && *cd.early_ok != 0;
+  const int nxs[4] = {x - inc, x, x + inc, x}, nys[4] = {y, y - inc, y, y + inc};
+  for (int k = 0; k < nb; ++k) {
+    if (nxs[k] < 0 || nxs[k] >= pm.W || nys[k] < 0 || nys[k] >= pm.H) continue;
+    const long long j = (long long)nys[k] * pm.W + nxs[k];
+    const Cand cand{f.nx[j], f.ny[j], f.nz[j], f.a[j], f.b[j], f.c[j]};
+    const double cost = eval_plane_chain<CS, SRC>(cd, lut, s_m[wave], v, x, y, cand.nx, cand.ny, cand.nz, cand.a, cand.b, cand.c, best_cost,
+                                                    use_thresh, lane);
+    if (cost < best_cost) { best_cost = cost; best = cand; changed = true; }
+  }
+  if (changed && lane == 0) store_plane(f, i, best.nx, best.ny, best.nz, best.a, best.b, best.c, best_cost);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSPatchMatch::SpatialPropagation in the reference's order (cs_patchmatch.cc:163-216): the in-place
+// raster sweep makes pixel (x,y) depend on (x-inc,y) and (x,y-inc) only, so all pixels of one
+// anti-diagonal are independent.  A pixel tries the x-predecessor first, then the y-predecessor against
+// the updated minimum (:198-212); the first sweep row has only the former (:178-186), the first column only
+// the latter (:189-195).
+//
+// One workgroup evaluates both candidates of one pixel over the same window in one pass (the plane-independent half of
+// every tap is computed once).  Work split: cross-scale -> one wave per pyramid level; single-scale -> one wave per
+// chain pass.  No early exit: both candidate costs are needed in full when accepted.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSweepMaxWaves = 8;
+
+struct SweepShared {
+  LutMem lut;
+  ChainScratch m[kSweepMaxWaves];
+  double lvl[2][CSPM_MAX_LEVELS];  // cross-scale: exact level sums
+};
+
+// Both candidate costs at pixel (x,y) of view v; every wave of the workgroup calls it.  `both` = the two candidates differ
+// (otherwise only c0 is evaluated and cost1 = cost0).  Results are valid in wave 0 after the call.
+template <bool CS, int SRC>
+__device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, SweepShared &sh, int v, int x, int y, const Cand &c0,
+                                                const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
+  if (CS) {
+    // this wave's level `wave`: (cur_x, cur_y, cur_disp) after `wave` halvings (pre_cs_pc.cc:139-140,183-185)
+    if (wave < cd.levels) {
+      double d0 = c0.a * (double)x + c0.b * (double)y + c0.c, d1 = c1.a * (double)x + c1.b * (double)y + c1.c;
+      int cur_x = x, cur_y = y;
+      for (int s = 0; s < wave; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
+      const ChainLevel A = make_chain_level<SRC>(cd, wave, v, cur_x, cur_y);
+      ChainScratch &m = sh.m[wave];
+      double pa, pb, pc;
+      plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pa, pb, pc);  // :144-149
+      fill_tabs(m, 0, A, pa, pb, pc, lane);
+      double s0, s1;
+      if (both) {
+        plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
+        fill_tabs(m, 1, A, pa, pb, pc, lane);
+        wave_lds_fence();
+        double S[2][kMaxPasses];
+        chain_passes<SRC, 2>(cd, A, lut, m, lane, 0, 1, S);
+        store_parts<2>(m.part, S, 0, lane, 0, 1, A.passes);
+        wave_lds_fence();
+        s0 = finish_level(A, m.part, lane);
+        wave_lds_fence();
+        store_parts<2>(m.part, S, 1, lane, 0, 1, A.passes);
+        wave_lds_fence();
+        s1 = finish_level(A, m.part, lane);
+      } else {
+        wave_lds_fence();
+        double S[1][kMaxPasses];
+        chain_passes<SRC, 1>(cd, A, lut, m, lane, 0, 1, S);
+        store_parts<1>(m.part, S, 0, lane, 0, 1, A.passes);
+        wave_lds_fence();
+        s0 = s1 = finish_level(A, m.part, lane);
+      }
+      if (lane == 0) { sh.lvl[0][wave] = s0; sh.lvl[1][wave] = s1; }
+    }
+    __syncthreads();
+    cost0 = cost1 = 0.0;
+    if (wave == 0) {
+      for (int s = 0; s < cd.levels; ++s) {  // :182, levels in order
+        cost0 += sh.lvl[0][s] * cd.lv[s].wgt;
+        cost1 += sh.lvl[1][s] * cd.lv[s].wgt;
+      }
+    }
+  } else {
+    // single scale: the waves share the passes of the one level; chain sums meet in wave 0's scratch
+    const int nw = (int)(blockDim.x >> 6);
+    const ChainLevel A = make_chain_level<SRC>(cd, 0, v, x, y);
+    ChainScratch &m = sh.m[wave];
+    fill_tabs(m, 0, A, c0.a, c0.b, c0.c, lane);
+    if (both) fill_tabs(m, 1, A, c1.a, c1.b, c1.c, lane);
+    wave_lds_fence();
+    double S[2][kMaxPasses];
+    if (both) {
+      chain_passes<SRC, 2>(cd, A, lut, m, lane, wave, nw, S);
+    } else {
+      double S1[1][kMaxPasses];
+      chain_passes<SRC, 1>(cd, A, lut, m, lane, wave, nw, S1);
+#pragma unroll
+      for (int ps = 0; ps < kMaxPasses; ++ps) { S[0][ps] = S1[0][ps]; S[1][ps] = S1[0][ps]; }
+    }
+    __syncthreads();  // every wave is done reading its tables
+    store_parts<2>(sh.m[0].part, S, 0, lane, wave, nw, A.passes);
+    store_parts<2>(sh.m[1].part, S, 1, lane, wave, nw, A.passes);
+    __syncthreads();
+    cost0 = cost1 = 0.0;
+    if (wave == 0) {
+      cost0 = finish_level(A, sh.m[0].part, lane);
+      cost1 = both ? finish_level(A, sh.m[1].part, lane) : cost0;
+    }
+  }
+}
+
+// one launch per anti-diagonal k (sweep coordinates xs+ys == k, image x = inc>0 ? xs : W-1-xs); one workgroup per pixel
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
+  __shared__ SweepShared sh;
+  const Luts lut = load_luts(cd, sh.lut);
+  const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
+  const int cnt = ys_hi - ys_lo + 1;
+  const int b = (int)blockIdx.x;
+  const int v = b / cnt;  // grid = 2*cnt
+  const int ys = ys_lo + (b - v * cnt), xs = k - ys;
+  const int x = inc > 0 ? xs : pm.W - 1 - xs, y = inc > 0 ? ys : pm.H - 1 - ys;
+  const Field &f = pm.f[v];
+  const long long i = (long long)y * pm.W + x;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const bool have0 = xs > 0, have1 = ys > 0;
+  if (!have0 && !have1) return;
+  const long long jx = i - inc, jy = i - (long long)inc * pm.W;
+  const long long j0 = have0 ? jx : jy, j1 = have1 ? jy : jx;
+  const Cand c0{f.nx[j0], f.ny[j0], f.nz[j0], f.a[j0], f.b[j0], f.c[j0]};
+  const Cand c1{f.nx[j1], f.ny[j1], f.nz[j1], f.a[j1], f.b[j1], f.c[j1]};
+  const bool same01 = c0.nx == c1.nx && c0.ny == c1.ny && c0.nz == c1.nz && c0.a == c1.a && c0.b == c1.b && c0.c == c1.c;
+  double cost0, cost1;
+  eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, have0 && have1 && !same01, wave, lane, cost0, cost1);
+  if (threadIdx.x == 0) {
+    double best_cost = f.cost[i];
+    int pick = -1;
+    if (have0 && cost0 < best_cost) { best_cost = cost0; pick = 0; }
+    if (have1 && cost1 < best_cost) { best_cost = cost1; pick = 1; }
+    if (pick >= 0) {
+      const Cand &w = pick == 0 ? c0 : c1;
+      store_plane(f, i, w.nx, w.ny, w.nz, w.a, w.b, w.c, best_cost);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same raster sweep as ONE persistent launch (default): workgroups pull pixels in diagonal-major
+// order from a device-wide counter and wait, per pixel, for the "done" flags of its two predecessors
+// instead of for a kernel boundary.  Dataflow instead of W+H-2 launches per sweep: a pixel starts as
+// soon as ITS predecessors are final, diagonals overlap, and the fixed cost per launch is gone.
+//
+// Inter-workgroup protocol (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1 never
+// refreshed by other CUs' stores): every word another workgroup may read -- the 7 doubles of a plane
+// and the done flag -- is written with 8-byte / 4-byte AGENT-scope atomic stores (write-through) and
+// read with agent-scope atomic loads (L1 bypass), both sides; the producer drains its stores
+// (s_waitcnt vmcnt(0)) before it stores the flag.  No fences, no reliance on placement or dispatch
+// order.  Deadlock freedom: pixels are claimed in an order in which predecessors come first, so every
+// flag a workgroup waits for belongs to a pixel already claimed by a running workgroup.  Every spin is
+// bounded (wall clock); a timeout raises ctrl[1] and all workgroups drain.
+// ------------------------------------------------------------------------------------------------
+struct Sweep {
+  unsigned int *ctrl;         // [0] next item, [1] error (sticky)
+  unsigned int *done[2];      // per view, per pixel: epoch of the last sweep that finalised the pixel
+  const unsigned int *start;  // start[k] = items (both views) on diagonals < k; W+H entries
+  unsigned int epoch, total;
+  long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
+};
+#ifdef CSPM_SWEEP_TRACE
+#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[(size_t)item * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define SWEEP_STAMP(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ double ld_agent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int epoch, unsigned int *err) {
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 255u) == 0u) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (wall_clock64() - t0 > 300000000LL) {  // 3 s of the 100 MHz constant clock
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
+  __shared__ SweepShared sh;
+  __shared__ double s_plane[2][6];
+  __shared__ unsigned int s_item;
+  __shared__ int s_ok;
+  const Luts lut = load_luts(cd, sh.lut);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int ndiag = pm.W + pm.H - 1;
+  int k = 0;
+  unsigned int next_item = 0;
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_load(&sw.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) next_item = sw.total;  // an earlier sweep failed
+    else next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (;;) {
+    if (threadIdx.x == 0) {
+      s_item = next_item;
+      s_ok = 1;
+      // claim the following item now: the atomic's latency hides behind this item's work.  Claims of a
+      // workgroup stay increasing, which is all the deadlock argument needs.
+      if (next_item < sw.total) next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned int item = s_item;
+    if (item >= sw.total) return;
+    SWEEP_STAMP(0);
+    while (k + 1 < ndiag && item >= sw.start[k + 1]) ++k;  // items of one workgroup only increase
+    const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
+    const int cnt = ys_hi - ys_lo + 1;
+    const int r = (int)(item - sw.start[k]);
+    const int v = r / cnt;
+    const int ys = ys_lo + (r - v * cnt), xs = k - ys;
+    const int x = inc > 0 ? xs : pm.W - 1 - xs, y = inc > 0 ? ys : pm.H - 1 - ys;
+    const Field &f = pm.f[v];
+    const long long i = (long long)y * pm.W + x;
+    const long long jx = i - inc, jy = i - (long long)inc * pm.W;
+    const bool have0 = xs > 0, have1 = ys > 0;
+    SWEEP_STAMP(1);
+    // 1. wait for the predecessors: lanes 0 and 1 of wave 0 poll one flag each
+    if (wave == 0 && lane < 2) {
+      const bool need = lane == 0 ? have0 : have1;
+      if (need && !wait_done(sw.done[v] + (lane == 0 ? jx : jy), sw.epoch, &sw.ctrl[1])) s_ok = 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    asm volatile("" ::: "memory");
+    SWEEP_STAMP(2);
+    // 2. both candidate costs in one pass over the window
+    double cost0 = 0.0, cost1 = 0.0;
+    bool eval0 = false, eval1 = false;
+    if (have0 || have1) {
+      // with one candidate missing, both slots hold the existing one (the duplicate is computed once)
+      const long long j0 = have0 ? jx : jy, j1 = have1 ? jy : jx;
+      const Cand c0{ld_agent(f.nx + j0), ld_agent(f.ny + j0), ld_agent(f.nz + j0), ld_agent(f.a + j0), ld_agent(f.b + j0), ld_agent(f.c + j0)};
+      const Cand c1{ld_agent(f.nx + j1), ld_agent(f.ny + j1), ld_agent(f.nz + j1), ld_agent(f.a + j1), ld_agent(f.b + j1), ld_agent(f.c + j1)};
+      if (wave == 0 && lane == 0) {
+        s_plane[0][0] = c0.nx; s_plane[0][1] = c0.ny; s_plane[0][2] = c0.nz; s_plane[0][3] = c0.a; s_plane[0][4] = c0.b; s_plane[0][5] = c0.c;
+        s_plane[1][0] = c1.nx; s_plane[1][1] = c1.ny; s_plane[1][2] = c1.nz; s_plane[1][3] = c1.a; s_plane[1][4] = c1.b; s_plane[1][5] = c1.c;
+      }
+      // Result-preserving shortcuts (no arithmetic skipped that could change an outcome):
+      //  * both predecessors hold bitwise the same plane (very common once the sweep has passed over them): the second
+      //    evaluation would return the bits of the first and `cost1 < min(cur, cost0)` would fail;
+      //  * a predecessor holds bitwise the pixel's OWN plane: its cost here is the stored min_cost (same function, same
+      //    pixel, same plane), and `cost < min_cost` fails.  The own plane is only ever written by this workgroup.
+      const Cand own{f.nx[i], f.ny[i], f.nz[i], f.a[i], f.b[i], f.c[i]};
+      const bool same01 = c0.nx == c1.nx && c0.ny == c1.ny && c0.nz == c1.nz && c0.a == c1.a && c0.b == c1.b && c0.c == c1.c;
+      const bool trust = pm.trust_cost != 0;
+      const bool own0 = trust && c0.nx == own.nx && c0.ny == own.ny && c0.nz == own.nz && c0.a == own.a && c0.b == own.b && c0.c == own.c;
+      const bool own1 = trust && c1.nx == own.nx && c1.ny == own.ny && c1.nz == own.nz && c1.a == own.a && c1.b == own.b && c1.c == own.c;
+      eval0 = have0 && !own0;
+      eval1 = have1 && !own1 && !(have0 && same01);
+      SWEEP_STAMP(3);
+      if (eval0 && eval1) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, true, wave, lane, cost0, cost1);
+      } else if (eval0) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c0, false, wave, lane, cost0, cost1);
+      } else if (eval1) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0);
+      }
+    }
+    SWEEP_STAMP(4);
+    SWEEP_STAMP(5);
+    // 3. accept (x-predecessor first, then y-predecessor against the updated minimum), publish, raise the flag
+    if (wave == 0 && lane == 0) {
+      double best_cost = f.cost[i];  // own pixel: nobody else writes it during the sweep
+      int pick = -1;
+      if (eval0 && cost0 < best_cost) { best_cost = cost0; pick = 0; }
+      if (eval1 && cost1 < best_cost) { best_cost = cost1; pick = 1; }
+      if (pick >= 0) {
+        st_agent(f.nx + i, s_plane[pick][0]); st_agent(f.ny + i, s_plane[pick][1]); st_agent(f.nz + i, s_plane[pick][2]);
+        st_agent(f.a + i, s_plane[pick][3]); st_agent(f.b + i, s_plane[pick][4]); st_agent(f.c + i, s_plane[pick][5]);
+        st_agent(f.cost + i, best_cost);
+      }
+      SWEEP_STAMP(6);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the plane is in memory before the flag can be seen
+      __hip_atomic_store(sw.done[v] + i, sw.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      SWEEP_STAMP(7);
+    }
+    __syncthreads();  // s_item / s_plane / scratch are reused by the next item
+  }
+}
+
+}  // namespace cspm

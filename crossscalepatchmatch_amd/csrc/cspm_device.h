@@ -15,18 +15,13 @@ constexpr double kDoubleEps = 0.00000001;  // commfunc.h:26
 constexpr double kDoubleMax = 1.7976931348623157e308;  // commfunc.h:27 numeric_limits<double>::max()
 constexpr int kLutSize = 768;              // |dB|+|dG|+|dR| <= 765; the reference allocates 1000 (pre_cs_pc.cc:111)
 constexpr int kLutZero = 767;              // entry forced to 0.0: masked taps read it, so they add wgt*tmp = +0.0
-#ifndef CSPM_TABSIZE
-#define CSPM_TABSIZE 128
-#endif
-constexpr int kTabSize = CSPM_TABSIZE;              // per-wave tables a*qx / b*qy+c; 128 (not the 45 needed) keeps the two tables in different bank phases: 48 costs 6 %
-constexpr int kMaxRounds = 8;              // tap decode table in LDS: up to 2048 taps (window <= 45x45)
 constexpr int kWave = 64;
-constexpr int kEvalBlock = 256;            // 4 waves = 4 plane evaluations per workgroup
-constexpr int kDiagBlock = 512;            // raster-sweep kernel: 8 waves cooperate on one pixel (2 candidates x 4 slot blocks)
+constexpr int kEvalBlock = 256;            // chain engine, batch kernels: 4 waves = 4 plane evaluations per workgroup
 constexpr uint32_t kBorderPix = 0x00030303u;  // BORDER_THRES in B, G and R (cc/grd_cc.h:6)
 
 // One pyramid level of one PreSSPC/PreCSPC object (pre_cs_pc.h:41-56).
-// Images are stored PADDED: row stride Wp = W + 2*pad, image column x at index pad + x, pad = D + 2.
+// Images are stored PADDED: row stride Wp = W + 2*pad, image column x at index pad + x, pad = D + half + 8 (every
+// address a masked or clamped tap can form -- window overrun, disparity range -- stays inside the row's padding).
 // Pad cells hold the GRD border constant (BORDER_THRES = 3 for every channel and for the gradient,
 // cc/grd_cc.h:6), so the fused cost needs no border branch (cc/grd_cc.cpp:88-100, 134-147).
 // The PatchMatch kernels read the array-of-structs `px`: one 12-byte element per pixel = packed colour
@@ -68,9 +63,6 @@ struct Cost {
   int half;    // half_wnd_
   int n;       // 2*half+1
   int T;       // n*n taps
-  int groups;  // ceil(T/64)
-  int rounds;  // ceil(groups/4): taps are processed 256 at a time
-  const uint32_t *dec; // tap decode table, rounds*256 entries: dx | dy<<8, bit 31 set for t >= T
   const int *early_ok;    // device flag: all scale weights, max_costs (and the cells of uploaded volumes) are >= 0
   const double *lut;      // lookup_exp_[i] = exp(-i/10), host-computed, kLutSize entries
   const double *lut_a;    // GRD colour term ALPHA*min(i*0.3333333333, TAU_CLR) (grd_cc.cpp:8-18), kLutSize entries
@@ -91,6 +83,7 @@ struct Pm {
   uint64_t seed;
   int rng_row_shared;
   int use_thresh; // early exit enabled
+  int trust_cost; // every stored min_cost is the cost of the stored plane at that pixel (false after cspm_set_planes)
   Field f[2];
 };
 

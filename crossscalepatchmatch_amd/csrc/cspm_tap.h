@@ -1,0 +1,157 @@
+// cspm_tap.h -- the arithmetic of ONE window tap of IPlaneCost::GetPlaneCost (pre_ss_pc.cc:94-110, pre_cs_pc.cc:157-179)
+// and the summation order shared by both tap engines (gfx950, wave64).
+//
+// Two engines evaluate plane costs:
+//   * cspm_rows.h  -- ONE LANE PER PIXEL: a wavefront owns 64 x-adjacent pixels of an image row and walks the window
+//                     serially; the other view's rows are staged through LDS.  Used where many pixels are evaluated
+//                     independently (InitRandomPlane, PlaneRefinement, ViewPropagation): >= 95 % of all taps.
+//   * cspm_chain.h -- ONE WAVEFRONT PER PIXEL: the window is spread over the lanes.  Used where the pixel order is
+//                     serial (the raster sweep of SpatialPropagation) and for single evaluations (cspm_plane_cost_batch).
+// Both produce the same bits for the same (pixel, plane) because they add the same terms in the same order:
+//
+// Summation order "ROWTREE7" (the test oracle restates it as its CSOR_SUM_DEVICE order):
+//   - within window row dy, tap dx (0-based window column) is accumulated in dx order into partial sum S[dx % 7];
+//     row total R[dy] = (((((S0+S1)+S2)+S3)+S4)+S5)+S6;
+//   - level sum = balanced binary tree over R[0..63] (rows beyond the window and rows outside the image are +0.0;
+//     neighbours first).  An xor butterfly over 64 lanes computes it; so does one lane with six pending partial sums.
+//   Taps outside the image contribute nothing (the reference `continue`s; adding +0.0 is the same thing).
+#pragma once
+#include "cspm_device.h"
+
+#pragma clang fp contract(off)
+
+namespace cspm {
+
+constexpr int kRowMod = 7;     // interleaved partial sums per window row
+constexpr int kChainRows = 9;  // chain engine: 9 window rows x 7 chains = 63 lanes per pass
+constexpr int kMaxWnd = 45;    // window sizes up to 45: <= 64 rows for the row tree, <= 5 chain passes
+constexpr int kMaxPasses = (kMaxWnd + kChainRows - 1) / kChainRows;
+
+struct Luts {
+  const double *w;  // exp(-i/10), entry kLutZero = 0                 (pre_cs_pc.cc:111-114)
+  const double *a;  // ALPHA*min(i*0.3333333333,TAU_CLR)               (grd_cc.cpp:8-18), fused GRD path only
+};
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS queue of a wave is
+// in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+// One element with ONE global load and a 32-bit byte offset (saddr + voffset addressing, no 64-bit address math):
+// PixG = dwordx3 {g.lo, g.hi, pix}, PixC = dwordx4 {code0, code1, code2, pix}.  Held as 4 dwords either way.
+template <int SRC>
+__device__ __forceinline__ uint4 ld_elem(const char *base, int byte_off) {
+  if (SRC == kSrcCen) return *reinterpret_cast<const uint4 *>(base + (size_t)(unsigned)byte_off);
+  const u32x3 v = *reinterpret_cast<const u32x3_a4 *>(base + (size_t)(unsigned)byte_off);
+  return uint4{v.x, v.y, v.z, 0u};
+}
+template <int SRC> constexpr int elem_size() { return SRC == kSrcCen ? 16 : 12; }
+template <int SRC>
+__device__ __forceinline__ uint32_t pix_of(const uint4 &v) { return SRC == kSrcCen ? v.w : v.z; }
+__device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double((int)v.y, (int)v.x); }
+
+// myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
+// arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
+// TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
+__device__ __forceinline__ double grd_cell(const double *lut_a, uint32_t Iq, double Gq, uint32_t Io, double Go) {
+  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, Io, 0u);
+  const double grdDiff = __builtin_fmin(fabs(Gq - Go), 2.0);  // TAU_GRD
+  return lut_a[sad] + (1 - 0.1) * grdDiff;                    // ALPHA*clrDiff + (1-ALPHA)*grdDiff
+}
+// CenCC cell (cc/cen_cc.cc:54-62): Hamming distance of the two 80-bit codes, CENCUS_BIT = 80 when the other view's
+// pixel is outside the image (pad cells carry bit 31 in `pix`)
+__device__ __forceinline__ double cen_cell(const uint4 &q, const uint4 &o) {
+  const int eighty = 80;
+  const int ham = __popc(q.x ^ o.x) + __popc(q.y ^ o.y) + __popc(q.z ^ o.z);
+  const int cnt = ((int)o.w < 0) ? eighty : ham;
+  return (double)cnt;
+}
+template <int SRC>
+__device__ __forceinline__ double cell_of(const double *lut_a, const uint4 &own, const uint4 &other) {
+  if (SRC == kSrcCen) return cen_cell(own, other);
+  return grd_cell(lut_a, pix_of<SRC>(own), g_of(own), pix_of<SRC>(other), g_of(other));
+}
+
+// v_cvt_i32_f64 saturates and maps NaN to 0; written as asm because (int)double is undefined out of range.
+__device__ __forceinline__ int cvt_i32_sat(double x) {
+  int r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+  return r;
+}
+
+// The disparity of a tap split for the interpolation between two integer disparities (:166-175).
+//   valid  <=> static_cast<int>(q_disp) in [1, D-1]  <=> 1.0 <= q_disp < D        (else the "impossible disparity" branch)
+//   f      = that integer (clamped into [1, D-1] for invalid taps, so addresses stay inside the padded rows)
+//   fw     = floor_wgt = (f+1) - q_disp, ceil weight 1 - floor_wgt = q_disp - f
+// For a valid tap q_disp - f is the exact fraction (v_fract_f64), (f+1) - q_disp is exact too (Sterbenz: f >= 1), hence
+// floor_wgt == 1 - fract and 1 - floor_wgt == fract bit for bit: two instructions instead of five.
+// NaN / out-of-range q_disp saturate in v_cvt_i32_f64 (NaN -> 0) and fail `clamped == raw`, as x86 cvttsd2si's INT_MIN does.
+struct DispSplit {
+  bool valid;
+  int f;
+  double fw, fr;
+};
+__device__ __forceinline__ DispSplit split_disp(double q_disp, int Dm1, bool level_has_valid) {
+  DispSplit s;
+  const int f0 = cvt_i32_sat(q_disp);
+  s.f = med3_i32(f0, 1, Dm1);
+  s.valid = (s.f == f0) & level_has_valid;  // level_has_valid: D >= 2 (otherwise [1, D-1] is empty)
+  s.fr = __builtin_amdgcn_fract(q_disp);
+  s.fw = 1.0 - s.fr;
+  return s;
+}
+// interpolated cost of the tap, weighted (:173-176)
+__device__ __forceinline__ double tap_value(const DispSplit &s, double c0, double c1, double maxc, double wgt) {
+  double tmp = s.fw * c0 + s.fr * c1;
+  tmp = s.valid ? tmp : maxc;  // :169
+  return wgt * tmp;            // :176
+}
+
+// balanced binary tree over the 64 lanes (neighbours first): every lane ends with the same bits because a+b == b+a
+__device__ __forceinline__ double wave_tree_sum(double v) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// LDS copies of the two lookup tables, one per workgroup
+struct LutMem {
+  double w[kLutSize];
+  double a[kLutSize];
+};
+__device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem &m) {
+  for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) {
+    m.w[i] = i == kLutZero ? 0.0 : cd.lut[i];
+    m.a[i] = cd.lut_a[i];
+  }
+  __syncthreads();
+  return Luts{m.w, m.a};
+}
+
+// Work item index of this block.  Blocks are dealt round-robin to the 8 XCDs; give XCD k the k-th contiguous
+// eighth of the index space, so that each XCD's L2 holds one band of the image.
+__device__ __forceinline__ long long xcd_block() {
+  const long long per = (long long)gridDim.x / 8;  // gridDim.x is a multiple of 8
+  return (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+}
+
+__device__ __forceinline__ void store_plane(const Field &f, long long i, double nx, double ny, double nz, double a, double b,
+                                            double c, double cost) {
+  f.nx[i] = nx; f.ny[i] = ny; f.nz[i] = nz;
+  f.a[i] = a; f.b[i] = b; f.c[i] = c;
+  f.cost[i] = cost;
+}
+
+struct Cand { double nx, ny, nz, a, b, c; };
+
+}  // namespace cspm

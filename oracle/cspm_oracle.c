@@ -494,70 +494,62 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
   return wgt * tmp;
 }
 
-#define DEVICE_CHECK_EVERY 4 /* DEVICE early-exit checkpoints: after every 4th 64-tap group and at level end */
+#define ROWMOD_K 7   /* CSOR_SUM_DEVICE: interleaved partial sums per window row */
+#define ROWTREE_N 64 /* ... and a balanced binary tree over the window rows (window sizes up to 45 < 64) */
 
 /* aggregated cost of ONE level (inner loops of pre_cs_pc.cc:151-181 / pre_ss_pc.cc:82-115).
  * base/mul: total so far and the level's scale weight, used only for the early-exit test
- * base + partial*mul >= thresh.  Returns the level sum, or -1.0 if rejected early.
+ * base + partial*mul >= thresh (meaningful only when every term is >= 0; serial order: after every window row,
+ * device order: at the level end).  Returns 1 and the level sum in *sum, or 0 if rejected early.
  *
- * CSOR_SUM_DEVICE ("SLOT256"): tap t=(dy+half)*n+(dx+half) is accumulated, in t order,
- * into slot t%256; the 256 slots are reduced as r[l] = (p[l]+p[l+64]) + (p[l+128]+p[l+192]),
- * l<64, followed by an xor butterfly over r with offsets 1,2,4,8,16,32.  This is what one wavefront
- * (4 accumulators per lane) or four cooperating wavefronts compute. */
-static double slot_reduce(const double *p) {
-  double v[64], u[64];
-  for (int l = 0; l < 64; ++l) v[l] = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
-  for (int off = 1; off < 64; off <<= 1) {
-    for (int l = 0; l < 64; ++l) u[l] = v[l] + v[l ^ off];
-    memcpy(v, u, sizeof v);
-  }
-  return v[0];
-}
-
-static double level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double a, double b, double c,
-                         int sum_order, double base, double mul, double thresh, int use_thresh, long long *taps) {
+ * CSOR_SUM_SERIAL: one running sum over (dy outer, dx inner) -- the reference's order.
+ * CSOR_SUM_DEVICE ("ROWTREE7"):
+ *   - within window row dy (0-based), tap dx (0-based window column) is accumulated in dx order into the partial sum
+ *     S[dx % 7]; the row total is R[dy] = (((((S0+S1)+S2)+S3)+S4)+S5)+S6;
+ *   - the level sum is the balanced binary tree over R[0..63] (rows >= the window size and rows outside the image are
+ *     +0.0): pairs (0,1),(2,3).., then pairs of pairs, ... -- what an xor butterfly over 64 lanes computes, and what a
+ *     single lane computes with a binary-counter stack of six pending partial sums.
+ *   Taps outside the image are skipped (adding +0.0 changes nothing: every partial sum starts at +0.0).
+ *   Same terms as the serial order, other rounding. */
+static int level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double a, double b, double c,
+                      int sum_order, double base, double mul, double thresh, int use_thresh, long long *taps, double *sum) {
   const int half = pc->half_wnd, W = pc->wid[s], H = pc->hei[s];
   const uint8_t *I_p = pc->img[view][s] + ((size_t)cy * W + cx) * 3;
   long long nt = 0;
-  if (sum_order == CSOR_SUM_SERIAL) {
-    double acc = 0.0;
-    for (int dy = -half; dy <= half; ++dy) {
-      int q_y = cy + dy;
-      if (q_y >= 0 && q_y < H) {
-        const double q_disp_y = b * q_y + c;
-        for (int dx = -half; dx <= half; ++dx) {
-          int q_x = cx + dx;
-          if (q_x >= 0 && q_x < W) { acc += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y); ++nt; }
-        }
-        if (use_thresh && base + acc * mul >= thresh) { if (taps) *taps += nt; return -1.0; }
+  double acc = 0.0;
+  double R[ROWTREE_N];
+  for (int l = 0; l < ROWTREE_N; ++l) R[l] = 0.0;
+  for (int dy = -half; dy <= half; ++dy) {
+    int q_y = cy + dy;
+    if (q_y < 0 || q_y >= H) continue;
+    const double q_disp_y = b * q_y + c;
+    if (sum_order == CSOR_SUM_SERIAL) {
+      for (int dx = -half; dx <= half; ++dx) {
+        int q_x = cx + dx;
+        if (q_x >= 0 && q_x < W) { acc += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y); ++nt; }
       }
+      if (use_thresh && base + acc * mul >= thresh) { if (taps) *taps += nt; return 0; }
+    } else {
+      double S[ROWMOD_K];
+      for (int j = 0; j < ROWMOD_K; ++j) S[j] = 0.0;
+      for (int dx = -half; dx <= half; ++dx) {
+        int q_x = cx + dx;
+        if (q_x >= 0 && q_x < W) { S[(dx + half) % ROWMOD_K] += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y); ++nt; }
+      }
+      double r = S[0];
+      for (int j = 1; j < ROWMOD_K; ++j) r = r + S[j];
+      R[dy + half] = r;
     }
-    if (taps) *taps += nt;
-    return acc;
   }
-  const int n = 2 * half + 1, T = n * n, groups = (T + 63) / 64;
-  double part[256];
-  for (int l = 0; l < 256; ++l) part[l] = 0.0;
-  for (int g = 0; g < groups; ++g) {
-    for (int l = 0; l < 64; ++l) {
-      const int t = g * 64 + l;
-      if (t >= T) break;
-      const int q_y = cy + t / n - half, q_x = cx + t % n - half;
-      if (q_y >= 0 && q_y < H && q_x >= 0 && q_x < W) {
-        const double q_disp_y = b * q_y + c;
-        part[t % 256] += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y);
-        ++nt;
-      }
-    }
-    const int last = (g == groups - 1);
-    if (last || (use_thresh && (g % DEVICE_CHECK_EVERY) == DEVICE_CHECK_EVERY - 1)) {
-      const double tot = slot_reduce(part);
-      if (use_thresh && base + tot * mul >= thresh) { if (taps) *taps += nt; return -1.0; }
-      if (last) { if (taps) *taps += nt; return tot; }
-    }
+  if (sum_order != CSOR_SUM_SERIAL) {
+    for (int off = 1; off < ROWTREE_N; off <<= 1)
+      for (int l = 0; l < ROWTREE_N; l += 2 * off) R[l] = R[l] + R[l + off];
+    acc = R[0];
+    if (use_thresh && base + acc * mul >= thresh) { if (taps) *taps += nt; return 0; }
   }
   if (taps) *taps += nt;
-  return 0.0; /* T == 0 */
+  *sum = acc;
+  return 1;
 }
 
 double csor_pc_cost_thresh(const csor_pc *pc, int ref_x, int ref_y, const double norm[3],
@@ -566,8 +558,9 @@ double csor_pc_cost_thresh(const csor_pc *pc, int ref_x, int ref_y, const double
   if (taps) *taps = 0;
   if (!pc->cs) {
     /* PreSSPC::GetPlaneCost (pre_ss_pc.cc:74-118): uses plane.param() as is, one level */
-    double c = level_cost(pc, view, 0, ref_x, ref_y, param[0], param[1], param[2], sum_order, 0.0, 1.0, thresh, use_thresh, taps);
-    return c < 0.0 ? INFINITY : c;
+    double c;
+    if (!level_cost(pc, view, 0, ref_x, ref_y, param[0], param[1], param[2], sum_order, 0.0, 1.0, thresh, use_thresh, taps, &c)) return INFINITY;
+    return c;
   }
   /* PreCSPC::GetPlaneCost (pre_cs_pc.cc:133-188) */
   double cost = 0.0;
@@ -577,8 +570,9 @@ double csor_pc_cost_thresh(const csor_pc *pc, int ref_x, int ref_y, const double
     const double pt[3] = {(double)cur_x, (double)cur_y, cur_disp};
     double prm[3];
     csor_plane_param(norm, pt, prm); /* :144  Plane cur_plane(org_norm, Point3d(cur_x,cur_y,cur_disp)) */
-    double scale_cost = level_cost(pc, view, s, cur_x, cur_y, prm[0], prm[1], prm[2], sum_order, cost, pc->scale_wgt[s], thresh, use_thresh, taps);
-    if (scale_cost < 0.0) return INFINITY;
+    double scale_cost;
+    if (!level_cost(pc, view, s, cur_x, cur_y, prm[0], prm[1], prm[2], sum_order, cost, pc->scale_wgt[s], thresh, use_thresh, taps, &scale_cost))
+      return INFINITY;
     cost += scale_cost * pc->scale_wgt[s]; /* :182 */
     cur_y /= 2; cur_x /= 2; cur_disp /= 2.0; /* :183-185 */
   }

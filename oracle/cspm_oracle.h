@@ -31,8 +31,8 @@ enum { CSOR_LEFT = 0, CSOR_RIGHT = 1 };           /* commfunc.h:29  enum RefView
 /* summation order inside GetPlaneCost */
 enum {
   CSOR_SUM_SERIAL = 0,  /* reference order: dy outer, dx inner, one accumulator (pre_cs_pc.cc:151-181) */
-  CSOR_SUM_DEVICE = 1   /* device order "SLOT256": tap t -> slot t%256, per-slot accumulators in t order,
-                           r[l]=(p[l]+p[l+64])+(p[l+128]+p[l+192]), then xor-butterfly 1,2,..,32 over r */
+  CSOR_SUM_DEVICE = 1   /* device order "ROWTREE7": per window row, tap dx goes to partial sum S[dx % 7] in dx order; row total
+                           = ((((((S0+S1)+S2)+S3)+S4)+S5)+S6); level sum = balanced binary tree over the 64 (zero-padded) row totals */
 };
 
 /* propagation schedule of SpatialPropagation */

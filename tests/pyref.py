@@ -155,16 +155,21 @@ class PlaneCost:
             self.wgt = np.array([1.0])
         self.lut = np.array([math.exp(-i * 1.0 / 10.0) for i in range(1000)])
 
-    def _level(self, v, s, cx, cy, a, b, c):
+    def _level(self, v, s, cx, cy, a, b, c, rowmod=0):
+        """rowmod == 0: the reference's single running sum.  rowmod == K > 0: the device order of DESIGN.md 3.2 -- per window
+        row K interleaved partial sums (window column % K) combined left to right; the row totals (zero-padded to 64) are
+        combined by a balanced binary tree (neighbours first)."""
         w, h, D = self.dims[s]
         img, vol, maxc = self.img[v][s].astype(np.int64), self.vol[v][s], self.max_cost[v][s]
         cost = 0.0
+        rows = [0.0] * 64
         Ip = img[cy, cx]
         for dy in range(-self.half, self.half + 1):
             qy = cy + dy
             if qy < 0 or qy >= h:
                 continue
             qdy = b * qy + c
+            part = [0.0] * max(rowmod, 1)
             for dx in range(-self.half, self.half + 1):
                 qx = cx + dx
                 if qx < 0 or qx >= w:
@@ -173,21 +178,34 @@ class PlaneCost:
                 qd = a * qx + qdy
                 f = int(qd) if (qd == qd and abs(qd) < 2 ** 31) else -(2 ** 31)  # cvttsd2si
                 if f <= 0 or f >= D:
-                    cost += wgt * maxc
+                    term = wgt * maxc
                 else:
                     fw = (f + 1) - qd
-                    cost += wgt * (fw * vol[f, qy, qx] + (1 - fw) * vol[f + 1, qy, qx])
+                    term = wgt * (fw * vol[f, qy, qx] + (1 - fw) * vol[f + 1, qy, qx])
+                if rowmod:
+                    part[(dx + self.half) % rowmod] += term
+                else:
+                    cost += term
+            if rowmod:
+                row = part[0]
+                for j in range(1, rowmod):
+                    row = row + part[j]
+                rows[dy + self.half] = row
+        if rowmod:
+            while len(rows) > 1:  # neighbours first: (r0+r1), (r2+r3), ... then pairs of pairs
+                rows = [rows[i] + rows[i + 1] for i in range(0, len(rows), 2)]
+            cost = rows[0]
         return cost
 
-    def cost(self, x, y, norm, param, v):
+    def cost(self, x, y, norm, param, v, rowmod=0):
         if not self.cs:
-            return self._level(v, 0, x, y, param[0], param[1], param[2])
+            return self._level(v, 0, x, y, param[0], param[1], param[2], rowmod)
         cost = 0.0
         cur = param[0] * x + param[1] * y + param[2]
         cx, cy = x, y
         for s in range(len(self.dims)):
             a, b, c = plane_param(norm, [float(cx), float(cy), cur])
-            cost += self._level(v, s, cx, cy, a, b, c) * self.wgt[s]
+            cost += self._level(v, s, cx, cy, a, b, c, rowmod) * self.wgt[s]
             cy //= 2; cx //= 2; cur /= 2.0
         return cost
 

@@ -170,7 +170,8 @@ def test_scale_weights_small_level_counts(gpu_ctx, small_pair):
             o = np.zeros(8)
             assert po.lib().csor_scale_weights(sn, lam, o.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double))) == 0
             np.testing.assert_array_equal(gpu_ctx.scale_weights(), o[:sn])
-            assert abs(gpu_ctx.scale_weights().sum() - 1.0) < 1e-12  # rows of inv(M) sum to 1: M has unit row sums
+            if sn >= 2:
+                assert abs(gpu_ctx.scale_weights().sum() - 1.0) < 1e-12  # rows of inv(M) sum to 1: M (S >= 2) has unit row sums
 
 
 def test_errors(gpu_ctx, small_pair):

@@ -229,7 +229,8 @@ def test_device_resident_io_stream_and_timing(gpu_ctx, small_pair):
             np.testing.assert_array_equal(outs[v].cpu().numpy(), pm.dis(v))
         t = ctx.timing()
         assert t["init"]["launches"] == 1 and t["init"]["evals"] == 2 * w * h
-        assert t["refine"]["launches"] == 2 * po.lib().csor_refine_steps(small_pair["max_dis"])
+        # one launch per iteration runs all halving steps of PlaneRefinement; `evals` counts every candidate plane
+        assert t["refine"]["launches"] == 2 and t["refine"]["evals"] == 2 * 2 * w * h * po.lib().csor_refine_steps(small_pair["max_dis"])
         assert t["spatial"]["launches"] == 2 and t["view"]["launches"] == 4
         assert all(t[k]["ms"] > 0 for k in ("grd", "init", "spatial", "view", "refine"))
         assert ctx.taps_per_view_pass() == sum(pc.taps(x, y) for y in range(h) for x in range(w))

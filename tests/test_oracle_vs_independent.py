@@ -75,11 +75,12 @@ def test_volumes_and_max_cost(scale_num, lam):
     assert pc.volume(0, 0)[d, y, x] == want
 
 
+@pytest.mark.parametrize("wnd", [7, 9])
 @pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (3, 0.3), (5, 1.0)])
-def test_get_plane_cost_serial_order(scale_num, lam):
+def test_get_plane_cost_serial_order(scale_num, lam, wnd):
     l, r = _tiny(30, 22, 10, 2)
-    pc = po.PlaneCost(l, r, 10, 7, scale_num, lam)
-    ref = pyref.PlaneCost(l, r, 10, 7, scale_num, lam)
+    pc = po.PlaneCost(l, r, 10, wnd, scale_num, lam)
+    ref = pyref.PlaneCost(l, r, 10, wnd, scale_num, lam)
     rng = np.random.default_rng(8)
     for i in range(60):
         x, y, v = int(rng.integers(0, 30)), int(rng.integers(0, 22)), int(rng.integers(0, 2))
@@ -92,6 +93,7 @@ def test_get_plane_cost_serial_order(scale_num, lam):
         got = pc.cost(x, y, n, prm, v, po.SUM_SERIAL)
         assert got == ref.cost(x, y, n, prm, v), (i, x, y, v)
         dev = pc.cost(x, y, n, prm, v, po.SUM_DEVICE)
+        assert dev == ref.cost(x, y, n, prm, v, rowmod=7), (i, x, y, v)  # the device order, restated independently
         assert abs(dev - got) <= 1e-12 * max(1.0, abs(got))  # same terms, other summation order
 
 
@@ -108,7 +110,7 @@ def test_threshold_variant_is_result_preserving():
             for thr in (full * 0.5, full, np.nextafter(full, np.inf), full * 2):
                 c, taps = pc.cost_thresh(x, y, n, prm, v, order, thr)
                 if full >= thr:
-                    assert c == np.inf
+                    assert c == np.inf and taps <= pc.taps(x, y)
                 else:
                     assert c == full and taps == pc.taps(x, y)
     # exact tap count: interior pixel of a big-enough level has (2*17+1)^2 taps at level 0
