@@ -51,6 +51,7 @@ enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2 };
 
 struct cspm_ctx {
   int device = 0, ncu = 256;
+  int refine_chunk = 64;  // PlaneRefinement halving steps per launch (tuning knob, env CSPM_REFINE_CHUNK)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
   // images
@@ -176,7 +177,8 @@ inline unsigned row_grid(int W, int H, int views) {
   return (unsigned)nb;
 }
 inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
-inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * row_cap(c) * 16; }
+inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }
+inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * (row_cap(c) + row_ocap(c)) * 16; }
 
 inline unsigned eval_grid(long long items) {
   long long nb = (items + (kEvalBlock / kWave) - 1) / (kEvalBlock / kWave);
@@ -531,7 +533,7 @@ int do_init(cspm_ctx *c, const cspm_pm_params *p) {
   Pm pm = make_pm(c, p);
   {
     Timed t(c, CSPM_K_INIT, items);
-    LAUNCH_CS(k_init, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, row_cap(c));
+    LAUNCH_CS(k_init, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, row_cap(c), row_ocap(c));
   }
   HIPCHK(c, hipGetLastError());
   c->field_consistent = true;
@@ -608,7 +610,7 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   for (int v = 0; v < 2; ++v) {
     {
       Timed t(c, CSPM_K_VIEW, items);
-      LAUNCH_CS(k_view_eval, dim3(row_grid(c->W, c->H, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, v, c->vc, row_cap(c));
+      LAUNCH_CS(k_view_eval, dim3(row_grid(c->W, c->H, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, v, c->vc, row_cap(c), row_ocap(c));
     }
     {
       Timed t(c, CSPM_K_MISC, 0);
@@ -625,10 +627,14 @@ int do_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   const double z_iter = c->max_dis / 2.0, n_iter = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145
   int steps = 0;
   for (double z = z_iter; z >= 0.1; z /= 2.0) ++steps;   // kZStopThres_, cs_patchmatch.h:146
-  if (steps > 0) {
-    // all halving steps of the iteration in ONE launch: a pixel's steps depend only on its own earlier steps
-    Timed t(c, CSPM_K_REFINE, items * steps);
-    LAUNCH_CS(k_refine, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, iter, 0, steps, z_iter, n_iter, row_cap(c));
+  // several halving steps per launch: a pixel's steps depend only on its own earlier steps, so the lane keeps its plane in
+  // registers between them (c->refine_chunk steps per launch; one launch for all of them by default)
+  double z = z_iter, nn = n_iter;
+  for (int first = 0; first < steps; first += c->refine_chunk) {
+    const int cnt = std::min(c->refine_chunk, steps - first);
+    Timed t(c, CSPM_K_REFINE, items * cnt);
+    LAUNCH_CS(k_refine, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, iter, first, cnt, z, nn, row_cap(c), row_ocap(c));
+    for (int k = 0; k < cnt; ++k) { z /= 2.0; nn /= 2.0; }
   }
   HIPCHK(c, hipGetLastError());
   return CSPM_OK;
@@ -662,6 +668,7 @@ int cspm_create(cspm_ctx **out, int device) {
   cspm_ctx *c = new cspm_ctx();
   c->device = device;
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = getenv("CSPM_REFINE_CHUNK")) c->refine_chunk = std::max(1, atoi(e));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
     return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));

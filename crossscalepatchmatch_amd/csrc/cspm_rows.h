@@ -23,133 +23,395 @@
 namespace cspm {
 
 constexpr int kRowWaves = 8;                  // waves per workgroup (they share the two lookup tables)
+#ifndef CSPM_ROW_MINW
+#define CSPM_ROW_MINW 4                       // minimum waves per SIMD the register allocator must leave room for (row kernels)
+#endif
 constexpr int kRowBlock = kRowWaves * kWave;
 
-// element of the LDS strip: what a tap needs of the other view, 16 bytes so that one ds_read_b128 fetches it
-//   GRD: {g.lo, g.hi, pix, -}   census: {code0, code1, code2, pix}
-// The strip of a wave holds `cap` elements; rows_shared_bytes() sizes the dynamic LDS of a launch.
-struct RowShared {
-  LutMem lut;
-};
-constexpr int kStripRegs = 6;                 // strip elements a lane carries from global memory to LDS: strips of <= 384 elements
+// Two wave-private LDS strips per window row (sized by strip_capacity / own_capacity, carved from the launch's dynamic LDS):
+//   other view: 16-byte slots, see rd_cells();   own view: gradients (8 B) and colours (4 B) as two arrays (GRD, volumes),
+//   16-byte {code, colour} slots (census).
+constexpr int kStripRegs = 6;                 // other-view elements a lane carries from global memory to LDS: strips of <= 384 slots
+constexpr int kOwnRegs = 2;                   // own-view elements per lane: 64 centres + window <= 128
 __host__ __device__ inline int strip_capacity(int max_dis, int half) {
   const int want = kWave + 2 * half + max_dis + 2;  // 64 centres + window + disparity range (level 0 is the widest)
-  return want <= kStripRegs * kWave ? want : kStripRegs * kWave;  // wider than that: the level reads the other view from global memory
+  return want <= kStripRegs * kWave ? want : kStripRegs * kWave;  // wider than that: the level reads both views from global memory
+}
+__host__ __device__ inline int own_capacity(int half) { return kWave + 2 * half + 2; }
+
+// what a lane holds of one element on its way from global memory to LDS
+template <int SRC> struct StripReg { typedef u32x3 type; };
+template <> struct StripReg<kSrcCen> { typedef uint4 type; };
+template <int SRC>
+__device__ __forceinline__ typename StripReg<SRC>::type ld_strip(const char *row, int byte_off) {
+  if constexpr (SRC == kSrcCen) return *reinterpret_cast<const uint4 *>(row + (size_t)(unsigned)byte_off);
+  else return *reinterpret_cast<const u32x3_a4 *>(row + (size_t)(unsigned)byte_off);
 }
 
-// per-lane state of one level
+// GRD other-view slot k (16 bytes) = {gradient of column k (8 B), colour of column k, colour of the NEXT column towards larger
+// disparity (k-1 for the left view, k+1 for the right view)}: one ds_read_b128 gives a tap its first cell and the colour of
+// its second, one ds_read_b64 of the neighbouring slot the second gradient -- 24 bytes in two LDS instructions at the
+// full 256 B/clk (12-byte ds_read_b96 would run at 96 B/clk, 8-byte reads of 16-byte slots use half the banks).
+template <int SRC, int VIEW>
+__device__ __forceinline__ void rd_cells(const char *strip, int adr, uint4 &o0, uint4 &o1) {
+  constexpr int dirS = VIEW == 0 ? -16 : 16;
+  if constexpr (SRC == kSrcCen) {
+    o0 = *reinterpret_cast<const uint4 *>(strip + adr);
+    o1 = *reinterpret_cast<const uint4 *>(strip + adr + dirS);
+  } else {
+    const uint4 s0 = *reinterpret_cast<const uint4 *>(strip + adr);
+    const uint2 g1 = *reinterpret_cast<const uint2 *>(strip + adr + dirS);
+    o0 = uint4{s0.x, s0.y, s0.z, 0u};
+    o1 = uint4{g1.x, g1.y, s0.w, 0u};
+  }
+}
+template <int SRC> struct StageReg { uint4 v; };
+template <int SRC, int VIEW>
+__device__ __forceinline__ StageReg<SRC> ld_stage(const char *row, int byte_off) {
+  constexpr int E = elem_size<SRC>();
+  StageReg<SRC> r;
+  if constexpr (SRC == kSrcCen) {
+    r.v = *reinterpret_cast<const uint4 *>(row + (size_t)(unsigned)byte_off);
+  } else {
+    const u32x3 e = *reinterpret_cast<const u32x3_a4 *>(row + (size_t)(unsigned)byte_off);
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(row + (size_t)(unsigned)(byte_off + (VIEW == 0 ? -E : E) + 8));
+    r.v = uint4{e.x, e.y, e.z, nb};
+  }
+  return r;
+}
+// own-view strip: element of window column dx of a lane.  GRD / volumes: adr_g addresses the gradient array (8-byte stride),
+// adr_p the colour array (4-byte stride) -- consecutive lanes hit consecutive banks; census: adr_g addresses 16-byte slots.
+template <int SRC>
+__device__ __forceinline__ uint4 rd_own(const char *ostrip, int adr_g, int adr_p, int j) {
+  if constexpr (SRC == kSrcCen) {
+    return *reinterpret_cast<const uint4 *>(ostrip + adr_g + j * 16);
+  } else {
+    const uint32_t pix = *reinterpret_cast<const uint32_t *>(ostrip + adr_p + j * 4);
+    uint2 g{0u, 0u};
+    if constexpr (SRC == kSrcGrd) g = *reinterpret_cast<const uint2 *>(ostrip + adr_g + j * 8);
+    return uint4{g.x, g.y, pix, 0u};
+  }
+}
+template <int SRC>
+__device__ __forceinline__ void wr_own(char *ostrip, int ocap, int idx, const typename StripReg<SRC>::type &e) {
+  if constexpr (SRC == kSrcCen) {
+    *reinterpret_cast<uint4 *>(ostrip + idx * 16) = e;
+  } else {
+    if constexpr (SRC == kSrcGrd) *reinterpret_cast<uint2 *>(ostrip + idx * 8) = uint2{e.x, e.y};
+    *reinterpret_cast<uint32_t *>(ostrip + ocap * 8 + idx * 4) = e.z;
+  }
+}
+// base + f * K for a small compile-time K (one v_mad_i32_i24; K is an inline constant)
+template <int K>
+__device__ __forceinline__ int mad_const(int f, int base) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(f), "n"(K), "v"(base));
+  return r;
+}
+
+// per-level constants of a wave
 struct RowLevel {
-  int W, H, n, half, Dm1;
-  int Wp, pad;
+  int W, n, half, Dm1;
   bool has_valid;
-  double maxc, wgt;
-  const char *px, *opx;
+  double maxc;
   const double *vol;
   size_t slab;
 };
 
-// binary-counter stack for the row tree: pend[k] holds the sum of a completed block of 2^k rows
+// Row tree of the ROWTREE7 order as a binary counter: p<k> holds the sum of a completed block of 2^k window rows.
+// `idx` (the window row number) is wave-uniform: the cascade is scalar control flow around at most one add per level.
 struct RowTree {
-  double pend[6];
-  // add row total R as row number `idx` (0-based, wave-uniform): blocks of equal size merge, earlier rows on the left
+  double p0, p1, p2, p3, p4, p5;
   __device__ __forceinline__ void push(int idx, double R) {
     double t = R;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      if (((idx >> k) & 1) == 0) { pend[k] = t; return; }
-      t = pend[k] + t;
-    }
-    // idx = 63 (all ones): t is the complete 64-row tree; n <= 45, not reached
+    if ((idx & 1) == 0) { p0 = t; return; }
+    t = p0 + t;
+    if ((idx & 2) == 0) { p1 = t; return; }
+    t = p1 + t;
+    if ((idx & 4) == 0) { p2 = t; return; }
+    t = p2 + t;
+    if ((idx & 8) == 0) { p3 = t; return; }
+    t = p3 + t;
+    if ((idx & 16) == 0) { p4 = t; return; }
+    t = p4 + t;
+    p5 = t;  // idx & 32 == 0 always: windows have at most 45 rows
   }
   // the tree over 64 leaves whose rows >= count are +0.0: fold the pending blocks, small (late) ones first
   __device__ __forceinline__ double total(int count) const {
     double t = 0.0;
     bool have = false;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      if ((count >> k) & 1) {
-        t = have ? pend[k] + t : pend[k];
-        have = true;
-      }
-    }
+    if (count & 1) { t = p0; have = true; }
+    if (count & 2) { t = have ? p1 + t : p1; have = true; }
+    if (count & 4) { t = have ? p2 + t : p2; have = true; }
+    if (count & 8) { t = have ? p3 + t : p3; have = true; }
+    if (count & 16) { t = have ? p4 + t : p4; have = true; }
+    if (count & 32) { t = have ? p5 + t : p5; }
     return t;
   }
 };
 
-// One window row of one level for all 64 lanes.  EDGE: some lane's window leaves the image in x (per-tap mask).
-// STAGED: the other view's cells come from the LDS strip (else straight from global memory: volumes, or a wave whose
-// centres are too spread out for the strip).
-//   own_row   : byte address of element (row qy, padded column 0) of the own view
-//   lane_off  : byte offset of the lane's first tap (padded column pad + cx - half) * E
-//   strip_adr : LDS byte address of the strip element that holds other-view column (cx - half) -/+ 0 for this lane, i.e.
-//               tap dx at disparity f is at strip_adr + 16*dx + dirS*f  (dirS = -16 left view, +16 right view)
-template <int SRC, bool EDGE, bool STAGED>
-__device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, const char *own_row, const char *oth_row, int lane_off,
-                                           const char *strip, int strip_adr, int dirS, int dirE, uint32_t Ip, double pa, double rowterm,
-                                           double qx0_d, int e_lo, int e_span, int qy, int cx_lane) {
+// where the taps of one window row find their operands
+struct RowSrc {
+  // staged: LDS byte addresses of window column 0 of the lane (other strip at f = 0; own strip gradient / colour arrays)
+  const char *strip, *ostrip;
+  int adr_o, adr_g, adr_p;
+  // unstaged: image rows in global memory and the byte offset of the lane's window column 0
+  const char *own_row, *oth_row;
+  int lane_off;
+};
+
+// CNT consecutive taps (window columns g0 .. g0+CNT-1, CNT <= 7) of one window row for all 64 lanes, accumulated into the
+// partial sums S[0..CNT-1] (g0 is a multiple of 7, so tap g0+j belongs to S[j]).  Everything that varies with j is an
+// immediate: the taps form one basic block, and their LDS reads are in flight together.
+//   VIEW   : 0 = left view (other view read at x-f, x-f-1), 1 = right view (x+f, x+f+1)
+//   EDGE   : some lane's window leaves the image in x -> per-tap mask (e_rel = g0 - e_lo per lane, e_span)
+//   STAGED : operands come from the two LDS strips, else from global memory
+#ifndef CSPM_ROW_SUB
+#define CSPM_ROW_SUB 2  // taps whose memory round trips are overlapped (sub-batch of a group of 7): register pressure vs latency hiding
+#endif
+template <int SRC, int VIEW, bool EDGE, bool STAGED, int J0, int J1>
+__device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, int adr_o, int adr_g, int adr_p, int off_g,
+                                          uint32_t Ip, double pa, double rowterm, double &qx_d, int e_rel, int e_span, int qy, int cx_lane,
+                                          double S[kRowMod]) {
   constexpr int E = elem_size<SRC>();
+  constexpr int dirS = VIEW == 0 ? -16 : 16, dirE = VIEW == 0 ? -E : E;
+  constexpr int N = J1 - J0;
   const int lutzero = kLutZero;
+  // The taps are written stage by stage, not tap by tap: a tap is a chain of three dependent memory round trips (own
+  // element -> guide weight; disparity -> the two cells of the other view -> colour term), and the chains overlap only if
+  // the reads of one stage are issued back to back.
+  uint4 P[N], o0[N], o1[N];
+  double fr[N], wgt[N], tmp[N];
+  bool valid[N], in_img[N];
+  // stage 1: own elements
+#pragma unroll
+  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(R.ostrip, adr_g, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
+  // stage 2: disparities (pure arithmetic), then the cells of the other view
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int j = J0 + k;
+    const double q_disp = pa * qx_d + rowterm;  // :165
+    qx_d += 1.0;                                // exact: small integers
+    const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
+    fr[k] = d.fr;
+    valid[k] = d.valid;
+    in_img[k] = true;
+    if (EDGE) in_img[k] = (unsigned)(e_rel + j) <= (unsigned)e_span;
+    if (SRC == kSrcVolume) {
+      const int qx = in_img[k] ? cx_lane - A.half + g0 + j : cx_lane;
+      const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
+      tmp[k] = d.fw * v[0] + d.fr * v[A.slab];
+    } else if (STAGED) {
+      rd_cells<SRC, VIEW>(R.strip, mad_const<dirS>(d.f, adr_o) + j * 16, o0[k], o1[k]);
+    } else {
+      const int of = mad_const<dirE>(d.f, off_g);
+      o0[k] = ld_elem<SRC>(R.oth_row, of + j * E);
+      o1[k] = ld_elem<SRC>(R.oth_row, of + j * E + dirE);
+    }
+  }
+  // stage 3: guide weights (:161-164); outside the image: weight entry kLutZero = 0.0, the tap adds +0.0
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int sad = (int)__builtin_amdgcn_sad_u8(Ip, pix_of<SRC>(P[k]), 0u);
+    if (EDGE) sad = in_img[k] ? sad : lutzero;
+    wgt[k] = lut.w[sad];
+  }
+  // stage 4: cell costs (the colour term is the third round trip), interpolated (:171-175)
+  if (SRC != kSrcVolume) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double c0 = cell_of<SRC>(lut.a, P[k], o0[k]);
+      const double c1 = cell_of<SRC>(lut.a, P[k], o1[k]);
+      tmp[k] = (1.0 - fr[k]) * c0 + fr[k] * c1;
+    }
+  }
+  // stage 5: the "impossible disparity" branch (:166-169), weight (:176), accumulate
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double maxc = A.maxc;
+    const double t = valid[k] ? tmp[k] : maxc;
+    S[J0 + k] += wgt[k] * t;
+  }
+}
+
+// CNT consecutive taps (window columns g0 .. g0+CNT-1, CNT <= 7) of one window row for all 64 lanes, accumulated into the
+// partial sums S[0..CNT-1] (g0 is a multiple of 7, so tap g0+j belongs to S[j]).  Everything that varies with j is an
+// immediate.
+//   VIEW   : 0 = left view (other view read at x-f, x-f-1), 1 = right view (x+f, x+f+1)
+//   EDGE   : some lane's window leaves the image in x -> per-tap mask (e_rel = g0 - e_lo per lane, e_span)
+//   STAGED : operands come from the two LDS strips, else from global memory
+template <int SRC, int VIEW, bool EDGE, bool STAGED, int CNT>
+__device__ __forceinline__ void tap_group(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, uint32_t Ip, double pa, double rowterm,
+                                          double &qx_d, int e_rel, int e_span, int qy, int cx_lane, double S[kRowMod]) {
+  constexpr int E = elem_size<SRC>();
+  constexpr int SUB = CSPM_ROW_SUB;
+  const int adr_o = R.adr_o + g0 * 16, adr_g = R.adr_g + g0 * (SRC == kSrcCen ? 16 : 8), adr_p = R.adr_p + g0 * 4, off_g = R.lane_off + g0 * E;
+  tap_batch<SRC, VIEW, EDGE, STAGED, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel, e_span, qy,
+                                                                  cx_lane, S);
+  if constexpr (CNT > SUB)
+    tap_batch<SRC, VIEW, EDGE, STAGED, SUB, (CNT < 2 * SUB ? CNT : 2 * SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel,
+                                                                              e_span, qy, cx_lane, S);
+  if constexpr (CNT > 2 * SUB)
+    tap_batch<SRC, VIEW, EDGE, STAGED, 2 * SUB, CNT>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel, e_span, qy, cx_lane, S);
+}
+
+// One window row of one level for all 64 lanes -> row total R (ROWTREE7: seven interleaved partial sums, combined left to right)
+template <int SRC, int VIEW, bool EDGE, bool STAGED>
+__device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, const RowSrc &R, uint32_t Ip, double pa, double rowterm,
+                                           double qx0_d, int e_lo, int e_span, int qy, int cx_lane) {
   double S[kRowMod];
 #pragma unroll
   for (int j = 0; j < kRowMod; ++j) S[j] = 0.0;
   double qx_d = qx0_d;
-  for (int g0 = 0; g0 < A.n; g0 += kRowMod) {
-#pragma unroll
-    for (int j = 0; j < kRowMod; ++j) {
-      const int dx = g0 + j;
-      if (dx < A.n) {  // wave-uniform; always true for the usual 35 = 5 x 7
-        const uint4 P = ld_elem<SRC>(own_row, lane_off + dx * E);
-        int sad = (int)__builtin_amdgcn_sad_u8(Ip, pix_of<SRC>(P), 0u);
-        if (EDGE) sad = ((unsigned)(dx - e_lo) <= (unsigned)e_span) ? sad : lutzero;  // outside the image: weight entry 0.0
-        const double wgt = lut.w[sad];                                                // :161-164
-        const double q_disp = pa * qx_d + rowterm;                                    // :165
-        const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
-        double c0, c1;
-        if (SRC == kSrcVolume) {
-          int qx = cx_lane - A.half + dx;
-          if (EDGE) qx = ((unsigned)(dx - e_lo) <= (unsigned)e_span) ? qx : cx_lane;
-          const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
-          c0 = v[0];
-          c1 = v[A.slab];
-        } else if (STAGED) {
-          const int adr = strip_adr + __mul24(dirS, d.f) + dx * 16;
-          const uint4 o0 = *reinterpret_cast<const uint4 *>(strip + adr);
-          const uint4 o1 = *reinterpret_cast<const uint4 *>(strip + adr + dirS);
-          c0 = cell_of<SRC>(lut.a, P, o0);
-          c1 = cell_of<SRC>(lut.a, P, o1);
-        } else {
-          const int of = lane_off + dx * E + __mul24(dirE, d.f);
-          c0 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(oth_row, of));
-          c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(oth_row, of + dirE));
-        }
-        S[j] += tap_value(d, c0, c1, A.maxc, wgt);
-        qx_d += 1.0;  // exact: small integers
-      }
-    }
+  const int full = A.n / kRowMod * kRowMod;
+  int g0 = 0;
+  for (; g0 < full; g0 += kRowMod)
+    tap_group<SRC, VIEW, EDGE, STAGED, kRowMod>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
+  // window sizes that are not a multiple of 7 (the usual 35 is): the remaining 1..6 taps
+  switch (A.n - full) {
+#define CSPM_TAIL(K) case K: tap_group<SRC, VIEW, EDGE, STAGED, K>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S); break;
+    CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
+#undef CSPM_TAIL
+    default: break;
   }
-  double R = S[0];
+  double Rsum = S[0];
 #pragma unroll
-  for (int j = 1; j < kRowMod; ++j) R = R + S[j];
-  return R;
+  for (int j = 1; j < kRowMod; ++j) Rsum = Rsum + S[j];
+  return Rsum;
 }
 
 // Per-wave description of the 64 evaluation centres of one pass (wave-uniform unless noted)
 struct RowCtx {
-  int view, y;       // all lanes evaluate in row y of `view`
+  int y;             // all lanes evaluate in row y
   int lane;
-  char *strip;       // this wave's LDS strip, `cap` elements of 16 bytes
-  int cap;
+  char *strip;       // this wave's other-view strip, `cap` slots of 16 bytes
+  char *ostrip;      // this wave's own-view strip, `ocap` elements (16 bytes reserved each)
+  int cap, ocap;
 };
+__device__ __forceinline__ RowCtx make_row_ctx(unsigned char *smem, int y, int cap, int ocap) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char *base = reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * (size_t)(cap + ocap) * 16;
+  return RowCtx{y, (int)(threadIdx.x & 63), base, base + (size_t)cap * 16, cap, ocap};
+}
+
+// One level of eval_rows for a wave: centres cx (per lane) in row cy (uniform), plane (a, b, c per lane) -> level sum.
+// (Outlining it -- noinline, to make the caller park its long-lived state once per level -- was measured: 2.8x slower,
+// the LDS pointers degrade to flat pointers and the Cost block to scratch memory across the call.)
+#ifndef CSPM_LEVEL_INLINE
+#define CSPM_LEVEL_INLINE __forceinline__
+#endif
+template <int SRC, int VIEW>
+__device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int s, int cx, int cy, double a, double b,
+                                             double c) {
+  constexpr int E = elem_size<SRC>();
+  const int lane = ctx.lane;
+  const Level &L = cd.lv[s];
+  RowLevel A;
+  A.W = L.W; A.n = cd.n; A.half = cd.half; A.Dm1 = L.D - 1;
+  A.has_valid = L.D >= 2;
+  A.maxc = cd.max_cost[VIEW * CSPM_MAX_LEVELS + s];
+  A.vol = L.vol[VIEW];
+  A.slab = (size_t)L.W * (size_t)L.H;
+  const char *px, *opx;
+  if (SRC == kSrcCen) {
+    px = reinterpret_cast<const char *>(L.pc[VIEW]); opx = reinterpret_cast<const char *>(L.pc[1 - VIEW]);
+  } else {
+    px = reinterpret_cast<const char *>(L.px[VIEW]); opx = reinterpret_cast<const char *>(L.px[1 - VIEW]);
+  }
+  // the wave's span of centres: decides the strip windows and whether any lane needs the column mask
+  int cmin = cx, cmax = cx;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    cmin = min(cmin, __shfl_xor(cmin, off, kWave));
+    cmax = max(cmax, __shfl_xor(cmax, off, kWave));
+  }
+  cmin = __builtin_amdgcn_readfirstlane(cmin);
+  cmax = __builtin_amdgcn_readfirstlane(cmax);
+  const bool edge = (cmin - A.half < 0) | (cmax + A.half >= A.W);
+  // strip windows in padded columns.  Other view: the left view reads x-f-1 .. x-1, the right view x+1 .. x+f+1 (f in [1, D-1]).
+  const int D = L.D;
+  const int s_lo = VIEW == 0 ? L.pad + cmin - A.half - D : L.pad + cmin - A.half;
+  const int s_hi = VIEW == 0 ? L.pad + cmax + A.half : L.pad + cmax + A.half + D + 1;
+  const int s_len = SRC == kSrcVolume ? 0 : s_hi - s_lo + 1;
+  const int o_lo = L.pad + cmin - A.half, o_len = cmax - cmin + 2 * A.half + 1;
+  const bool staged = s_len <= ctx.cap && o_len <= ctx.ocap;  // wave-uniform
+  RowSrc R;
+  R.strip = ctx.strip; R.ostrip = ctx.ostrip;
+  R.adr_o = (L.pad + cx - A.half - s_lo) * 16;
+  R.adr_g = (cx - cmin) * (SRC == kSrcCen ? 16 : 8);
+  R.adr_p = ctx.ocap * 8 + (cx - cmin) * 4;
+  R.lane_off = (L.pad + cx - A.half) * E;
+  const uint32_t Ip = SRC == kSrcCen ? L.pc[VIEW][cy * L.Wp + L.pad + cx].pix : L.px[VIEW][cy * L.Wp + L.pad + cx].pix;
+  const double qx0_d = (double)(cx - A.half);
+  const int e_lo = max(0, A.half - cx);                           // first window column inside the image
+  const int e_span = min(A.n - 1, A.W - 1 - cx + A.half) - e_lo;  // last one, relative
+  RowTree tree;
+  const int dy_lo = max(0, A.half - cy), dy_hi = min(A.n - 1, L.H - 1 - cy + A.half);
+  for (int dy = 0; dy < dy_lo; ++dy) tree.push(dy, 0.0);
+  // The strips of window row dy+1 are fetched into registers while row dy is being evaluated and written to LDS afterwards:
+  // the LDS queue of a wave is in order, so one buffer per strip suffices (reads of row dy precede the writes of row dy+1).
+  // (Measured alternatives: a second other-view buffer written mid-row, so that the staging registers die early -- slower,
+  // the allocator parks other values instead; an outlined level function -- 2.8x slower, see above.)
+  StageReg<SRC> pre[kStripRegs];
+  typename StripReg<SRC>::type opre[kOwnRegs];
+  const size_t row_stride = (size_t)L.Wp * E;
+  R.own_row = px + (size_t)(cy - A.half + dy_lo) * row_stride;
+  R.oth_row = opx + (size_t)(cy - A.half + dy_lo) * row_stride;
+  const int pre_off = (s_lo + lane) * E, opre_off = (o_lo + lane) * E;
+  auto fetch = [&](const char *own_row, const char *oth_row) {
+#pragma unroll
+    for (int k = 0; k < kStripRegs; ++k)
+      if (lane + k * kWave < s_len) pre[k] = ld_stage<SRC, VIEW>(oth_row, pre_off + k * kWave * E);
+#pragma unroll
+    for (int k = 0; k < kOwnRegs; ++k)
+      if (lane + k * kWave < o_len) opre[k] = ld_strip<SRC>(own_row, opre_off + k * kWave * E);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < kStripRegs; ++k)
+      if (lane + k * kWave < s_len) *reinterpret_cast<uint4 *>(ctx.strip + (lane + k * kWave) * 16) = pre[k].v;
+#pragma unroll
+    for (int k = 0; k < kOwnRegs; ++k)
+      if (lane + k * kWave < o_len) wr_own<SRC>(ctx.ostrip, ctx.ocap, lane + k * kWave, opre[k]);
+  };
+  if (staged) {
+    fetch(R.own_row, R.oth_row);
+    wave_lds_fence();  // the previous level's strip reads are done
+    commit();
+  }
+  for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+    const int qy = cy - A.half + dy;
+    const bool more = dy < dy_hi;
+    if (staged) {
+      wave_lds_fence();
+      if (more) fetch(R.own_row + row_stride, R.oth_row + row_stride);
+    }
+    const double rowterm = b * (double)qy + c;  // q_disp_y, :155
+    double Rsum;
+    if (staged) {
+      Rsum = edge ? row_taps<SRC, VIEW, true, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
+                  : row_taps<SRC, VIEW, false, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+    } else {
+      Rsum = row_taps<SRC, VIEW, true, false>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+    }
+    tree.push(dy, Rsum);
+    if (staged && more) {
+      wave_lds_fence();
+      commit();
+    }
+    R.own_row += row_stride;
+    R.oth_row += row_stride;
+  }
+  return tree.total(dy_hi + 1);
+}
 
 // Aggregated plane cost of 64 candidates, one per lane, each at its own centre column `x` (per lane, inside the image)
-// of row ctx.y.  (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param() -- per lane.  Returns the cost per lane;
-// lanes whose candidate is proven not to beat `thresh` (per lane) may return +inf instead (checked at level ends, only
-// when use_thresh; the wave leaves early once every lane is rejected).
-template <bool CS, int SRC>
-__device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int x, double nx, double ny, double nz,
-                                            double pa, double pb, double pc, double thresh, bool use_thresh) {
-  constexpr int E = elem_size<SRC>();
-  const int lane = ctx.lane, view = ctx.view;
+// of row ctx.y of view VIEW.  (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param() -- per lane.  Returns the cost per
+// lane; lanes whose candidate is proven not to beat `thresh` (per lane) may return +inf instead (checked at level ends,
+// only when use_thresh; the wave leaves early once every lane is rejected).
+template <bool CS, int SRC, int VIEW>
+__device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut, const RowCtx &ctx, int x, double nx, double ny, double nz,
+                                                 double pa, double pb, double pc, double thresh, bool use_thresh) {
   double cost = 0.0;
   bool dead = false;
   double cur_disp = pa * (double)x + pb * (double)ctx.y + pc;  // pre_cs_pc.cc:139-140
@@ -168,92 +430,8 @@ __device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, con
       dot += nz * cur_disp;
       c = dot / denom;
     }
-    const Level &L = cd.lv[s];
-    RowLevel A;
-    A.W = L.W; A.H = L.H; A.n = cd.n; A.half = cd.half; A.Dm1 = L.D - 1;
-    A.Wp = L.Wp; A.pad = L.pad;
-    A.has_valid = L.D >= 2;
-    A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
-    A.vol = L.vol[view];
-    A.slab = (size_t)L.W * (size_t)L.H;
-    if (SRC == kSrcCen) {
-      A.px = reinterpret_cast<const char *>(L.pc[view]); A.opx = reinterpret_cast<const char *>(L.pc[1 - view]);
-    } else {
-      A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
-    }
-    const int cy = cur_y;  // wave-uniform
-    const int cx = cur_x;  // per lane
-    // the wave's span of centres: decides the strip window and whether any lane needs the column mask
-    int cmin = cx, cmax = cx;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      cmin = min(cmin, __shfl_xor(cmin, off, kWave));
-      cmax = max(cmax, __shfl_xor(cmax, off, kWave));
-    }
-    cmin = __builtin_amdgcn_readfirstlane(cmin);
-    cmax = __builtin_amdgcn_readfirstlane(cmax);
-    const bool edge = (cmin - A.half < 0) | (cmax + A.half >= A.W);
-    // strip window in padded columns: left view reads x-f-1 .. x-1, right view x+1 .. x+f+1  (f in [1, D-1])
-    const int D = L.D;
-    const int s_lo = view == 0 ? A.pad + cmin - A.half - D : A.pad + cmin - A.half;
-    const int s_hi = view == 0 ? A.pad + cmax + A.half : A.pad + cmax + A.half + D + 1;
-    const int s_len = s_hi - s_lo + 1;
-    const bool staged = SRC != kSrcVolume && s_len <= ctx.cap;  // wave-uniform
-    const int dirS = view == 0 ? -16 : 16, dirE = view == 0 ? -E : E;
-    const int lane_off = (A.pad + cx - A.half) * E;
-    const int strip_adr = (A.pad + cx - A.half - s_lo) * 16 + (view == 0 ? 0 : 0);
-    const uint32_t Ip = SRC == kSrcCen ? L.pc[view][cy * L.Wp + L.pad + cx].pix : L.px[view][cy * L.Wp + L.pad + cx].pix;
-    const double qx0_d = (double)(cx - A.half);
-    const int e_lo = max(0, A.half - cx);                               // first window column inside the image
-    const int e_span = min(A.n - 1, A.W - 1 - cx + A.half) - e_lo;      // last one, relative
-    RowTree tree;
-    const int dy_lo = max(0, A.half - cy), dy_hi = min(A.n - 1, A.H - 1 - cy + A.half);
-    for (int dy = 0; dy < dy_lo; ++dy) tree.push(dy, 0.0);
-    // The strip of window row dy+1 is fetched into registers while row dy is being evaluated and written to LDS afterwards:
-    // the LDS queue of a wave is in order, so one strip suffices (reads of row dy precede the writes of row dy+1).
-    uint4 pre[kStripRegs];
-    const size_t row_stride = (size_t)A.Wp * E;
-    const char *own_row = A.px + (size_t)(cy - A.half + dy_lo) * row_stride, *oth_row = A.opx + (size_t)(cy - A.half + dy_lo) * row_stride;
-    if (staged) {
-#pragma unroll
-      for (int k = 0; k < kStripRegs; ++k)
-        if (lane + k * kWave < s_len) pre[k] = ld_elem<SRC>(oth_row, (s_lo + lane + k * kWave) * E);
-      wave_lds_fence();  // the previous level's strip reads are done
-#pragma unroll
-      for (int k = 0; k < kStripRegs; ++k)
-        if (lane + k * kWave < s_len) *reinterpret_cast<uint4 *>(ctx.strip + (lane + k * kWave) * 16) = pre[k];
-    }
-    for (int dy = dy_lo; dy <= dy_hi; ++dy) {
-      const int qy = cy - A.half + dy;
-      const bool more = dy < dy_hi;
-      if (staged) {
-        wave_lds_fence();
-        if (more) {
-#pragma unroll
-          for (int k = 0; k < kStripRegs; ++k)
-            if (lane + k * kWave < s_len) pre[k] = ld_elem<SRC>(oth_row + row_stride, (s_lo + lane + k * kWave) * E);
-        }
-      }
-      const double rowterm = b * (double)qy + c;  // q_disp_y, :155
-      double R;
-      if (staged) {
-        R = edge ? row_taps<SRC, true, true>(A, lut, own_row, oth_row, lane_off, ctx.strip, strip_adr, dirS, dirE, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
-                 : row_taps<SRC, false, true>(A, lut, own_row, oth_row, lane_off, ctx.strip, strip_adr, dirS, dirE, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
-      } else {
-        R = row_taps<SRC, true, false>(A, lut, own_row, oth_row, lane_off, ctx.strip, strip_adr, dirS, dirE, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
-      }
-      tree.push(dy, R);
-      if (staged && more) {
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < kStripRegs; ++k)
-          if (lane + k * kWave < s_len) *reinterpret_cast<uint4 *>(ctx.strip + (lane + k * kWave) * 16) = pre[k];
-      }
-      own_row += row_stride;
-      oth_row += row_stride;
-    }
-    const double sc = tree.total(dy_hi + 1);
-    if (CS) cost += sc * L.wgt;  // :182
+    const double sc = level_rows<SRC, VIEW>(cd, lut, ctx, s, cur_x, cur_y, a, b, c);
+    if (CS) cost += sc * cd.lv[s].wgt;  // :182
     else cost = sc;
     if (use_thresh) {
       dead = dead | (cost >= thresh);
@@ -264,6 +442,12 @@ __device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, con
     cur_disp /= 2.0;
   }
   return dead ? __builtin_inf() : cost;
+}
+template <bool CS, int SRC>
+__device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int view, int x, double nx, double ny,
+                                            double nz, double pa, double pb, double pc, double thresh, bool use_thresh) {
+  return view == 0 ? eval_rows_view<CS, SRC, 0>(cd, lut, ctx, x, nx, ny, nz, pa, pb, pc, thresh, use_thresh)
+                   : eval_rows_view<CS, SRC, 1>(cd, lut, ctx, x, nx, ny, nz, pa, pb, pc, thresh, use_thresh);
 }
 
 // pixel run of this wave: item = (view, y, 64-pixel segment), XCD-banded.  Returns false past the end.
@@ -287,15 +471,14 @@ __device__ __forceinline__ bool row_item(int W, int H, int views, RowItem &it) {
 // CSPatchMatch::InitRandomPlane  (cs_patchmatch.cc:115-148)
 // ------------------------------------------------------------------------------------------------
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock) void k_init(Cost cd, Pm pm, int cap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
   if (!row_item(pm.W, pm.H, 2, it)) return;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx{it.v, it.y, lane, reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * cap * 16, cap};
+  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;  // tail lanes shadow the last pixel
   const long long i = (long long)it.y * pm.W + x;
@@ -321,7 +504,7 @@ __global__ __launch_bounds__(kRowBlock) void k_init(Cost cd, Pm pm, int cap) {
   const double nx = r0 * inv, ny = r1 * inv, nz = r2 * inv;
   double a, b, c;
   plane_param(nx, ny, nz, (double)x, (double)it.y, rand_dis, a, b, c);  // :141-142
-  const double cost = eval_rows<CS, SRC>(cd, lut, ctx, x, nx, ny, nz, a, b, c, kDoubleMax, false);  // :143-144
+  const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, nx, ny, nz, a, b, c, kDoubleMax, false);  // :143-144
   if (live) store_plane(pm.f[it.v], i, nx, ny, nz, a, b, c, cost);
 }
 
@@ -330,15 +513,14 @@ __global__ __launch_bounds__(kRowBlock) void k_init(Cost cd, Pm pm, int cap) {
 // pixel's steps depend only on that pixel's own earlier steps, so the lane keeps its plane in registers across them.
 // ------------------------------------------------------------------------------------------------
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock) void k_refine(Cost cd, Pm pm, int iter, int first_step, int nsteps, double z_iter, double n_iter, int cap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm pm, int iter, int first_step, int nsteps, double z_iter, double n_iter, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
   if (!row_item(pm.W, pm.H, 2, it)) return;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx{it.v, it.y, lane, reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * cap * 16, cap};
+  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;
   const long long i = (long long)it.y * pm.W + x;
@@ -361,7 +543,7 @@ __global__ __launch_bounds__(kRowBlock) void k_refine(Cost cd, Pm pm, int iter, 
     const double nx = d0 * inv, ny = d1 * inv, nz = d2 * inv;
     double a, b, c;
     plane_param(nx, ny, nz, (double)x, (double)it.y, pz, a, b, c);             // :330
-    const double cost = eval_rows<CS, SRC>(cd, lut, ctx, x, nx, ny, nz, a, b, c, cur_min, use_thresh);
+    const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, nx, ny, nz, a, b, c, cur_min, use_thresh);
     if (cost < cur_min) {                                                      // :335-338
       cnx = nx; cny = ny; cnz = nz; ca = a; cb = b; cc = c;
       cur_min = cost;
@@ -391,15 +573,14 @@ struct ViewCand {
 };
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
   if (!row_item(pm.W, pm.H, 1, it)) return;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx{v, it.y, lane, reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * cap * 16, cap};
+  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;
   const int y = it.y;
@@ -418,7 +599,7 @@ __global__ __launch_bounds__(kRowBlock) void k_view_eval(Cost cd, Pm pm, int v, 
   plane_param(nx, ny, nz, (double)ex, (double)y, disp, a, b, c);          // :263-265
   const double thr = dst.cost[(long long)y * pm.W + ex];
   const bool use_thresh = pm.use_thresh != 0 && *cd.early_ok != 0;
-  double cost = eval_rows<CS, SRC>(cd, lut, ctx, ex, nx, ny, nz, a, b, c, use_thresh ? thr : kDoubleMax, use_thresh);  // :266-267
+  double cost = eval_rows<CS, SRC>(cd, lut, ctx, v, ex, nx, ny, nz, a, b, c, use_thresh ? thr : kDoubleMax, use_thresh);  // :266-267
   if (!inside) cost = __builtin_inf();
   if (live) {
     vc.cost[i] = cost;

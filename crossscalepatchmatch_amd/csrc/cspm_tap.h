@@ -58,8 +58,11 @@ __device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double
 // myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
 // arithmetic on the pad cells.  |dR|+|dG|+|dB| is an exact small integer, so ALPHA*min(sum*0.3333333333,
 // TAU_CLR) is a table of the SAD; min(.,TAU_GRD) on finite values is v_min_f64.
+// The colour term saturates at SAD = 31 (31 * 0.3333333333 > TAU_CLR = 10): the table is read through min(SAD, 31), so
+// its 32 live entries occupy 32 distinct LDS bank pairs and the gather is conflict-free whatever the 64 SADs are.
+constexpr unsigned kClrSat = 31;
 __device__ __forceinline__ double grd_cell(const double *lut_a, uint32_t Iq, double Gq, uint32_t Io, double Go) {
-  const int sad = (int)__builtin_amdgcn_sad_u8(Iq, Io, 0u);
+  const unsigned sad = min(__builtin_amdgcn_sad_u8(Iq, Io, 0u), kClrSat);
   const double grdDiff = __builtin_fmin(fabs(Gq - Go), 2.0);  // TAU_GRD
   return lut_a[sad] + (1 - 0.1) * grdDiff;                    // ALPHA*clrDiff + (1-ALPHA)*grdDiff
 }
@@ -127,13 +130,11 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
 // LDS copies of the two lookup tables, one per workgroup
 struct LutMem {
   double w[kLutSize];
-  double a[kLutSize];
+  double a[kClrSat + 1];  // 256 bytes = one LDS row: entry i lives in banks 2i, 2i+1
 };
 __device__ __forceinline__ Luts load_luts(const Cost &cd, LutMem &m) {
-  for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) {
-    m.w[i] = i == kLutZero ? 0.0 : cd.lut[i];
-    m.a[i] = cd.lut_a[i];
-  }
+  for (int i = threadIdx.x; i < kLutSize; i += blockDim.x) m.w[i] = i == kLutZero ? 0.0 : cd.lut[i];
+  if (threadIdx.x <= kClrSat) m.a[threadIdx.x] = cd.lut_a[threadIdx.x];
   __syncthreads();
   return Luts{m.w, m.a};
 }
