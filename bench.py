@@ -2,12 +2,17 @@
 """bench.py -- disparity throughput of the PatchMatch-stereo hot path on MI355X.
 
 A "step" = one stereo pair through the whole timed region of the reference's "Total Time"
-(main.cc:92-126): plane-cost construction (pyramid + GRD cost volumes of both views and all levels) +
+(main.cc:92-126): plane-cost construction (pyramid + GRD cost of both views and all levels) +
 CSPatchMatch::PatchMatch(3 iterations) + PlaneToDisp for both views, with the input images already
 resident in HBM.  Workload at N=1: BASELINE.json configs[2] = KITTI-size 1242x375, max_dis=128, GRD,
 use_cs=true (5 levels, reg_lambda=0.3), synthetic pair (no dataset in the image).
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank processes its own K pairs
 (weak scaling, no data-path collective), value = all pairs' pixels / max-over-ranks time.
+`python bench.py --gpus N` without a launcher spawns the N ranks itself.
+
+Pairs are independent units: by default three of them are in flight per GPU (three contexts, three HIP streams), so the
+CUs the raster sweep of one pair leaves idle (short anti-diagonals) evaluate the other pair's planes; all K pairs
+complete inside the timed region.  --in-flight 1 gives the one-pair-at-a-time number.
 
 Prints ONE JSON line (rank 0).
 """
@@ -25,49 +30,64 @@ if ROOT not in sys.path:
 
 BYTES_PER_TAP = 19  # 3 B guide pixel + 2 x 8 B cost cells per window tap (f64 volume)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# VALU issue: one wave64 instruction occupies its SIMD for 4.1 shader cycles, f64 and 32-bit alike (measured:
+# tools/ubench/valu_issue.hip, profiles/r02_valu_issue.txt; = the guide's 78.6 TFLOP/s f64 vector peak, 2 flop per lane
+# per FMA); 256 CUs x 4 SIMDs.  The shader clock under this kernel is taken from the same PMC run as the instruction count.
+VALU_CYCLES_PER_WINSTR = 4.1
+N_SIMD = 1024
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_refine_pmc.json")
 
 
-def cpu_baseline(cfg, l, r, device_index=0):
-    """The oracle (kind "port": the reference itself needs OpenCV/gflags and cannot be built here) in
-    reference order on a bounded centred crop of the same pair, on this box's host cores."""
+def cpu_baseline(device_index=0):
+    """The oracle (kind "port": the reference itself needs OpenCV/gflags and cannot be built here) in REFERENCE ORDER
+    (serial raster sweep, serial window sum, OpenMP over the rows of init/refinement as the reference) on the whole of
+    BASELINE.json configs[0] (C1: 450x375, max_dis=60, GRD, single scale) on this box's host cores, next to the GPU on the
+    same pair, seed and schedule -- which also gives the north-star parity figure (disparities within 0.5 px)."""
     from oracle import pyoracle as po
-    cw, ch = min(cfg["w"], 288), min(cfg["h"], 160)
-    x0, y0 = (cfg["w"] - cw) // 2, (cfg["h"] - ch) // 2
-    lc = np.ascontiguousarray(l[y0:y0 + ch, x0:x0 + cw])
-    rc = np.ascontiguousarray(r[y0:y0 + ch, x0:x0 + cw])
-    threads = max(1, min(os.cpu_count() or 1, ch))
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import synth
+    cfg, l, r, _, _ = synth.make_config("C1")
+    threads = max(1, min(os.cpu_count() or 1, cfg["h"]))
     t0 = time.perf_counter()
-    pc = po.PlaneCost(lc, rc, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
-    pm = po.PatchMatch(lc, rc, cfg["max_dis"], cfg["dis_scale"])
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
     pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL, threads=threads)
     dt = time.perf_counter() - t0
-    taps = sum(pc.taps(x, y) for y in range(ch) for x in range(cw)) * (pm.evals() // (cw * ch))
-    # the north-star parity figure on the same crop: HIP path vs this CPU run (identical inputs, seeds, schedule)
-    import crossscalepatchmatch_amd as cs
     g = cs.StereoContext(device_index)
-    g.set_images(lc, rc)
+    g.set_images(l, r)
+    g.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    g.patchmatch(3, seed=12345, schedule=cs.SCHED_RASTER)  # warm-up
+    g.synchronize()
+    t1 = time.perf_counter()
+    g.set_images(l, r)
     g.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
     g.patchmatch(3, seed=12345, schedule=cs.SCHED_RASTER)
+    g.synchronize()
+    gdt = time.perf_counter() - t1
+    taps = g.taps_per_view_pass() * 2 * (pm.evals() // (2 * cfg["w"] * cfg["h"]))
     diff = [np.abs(g.disparity_f64(v) - pm.disp_f64(v)) for v in (0, 1)]
     g.close()
+    mpix = cfg["w"] * cfg["h"] / 1e6
     return {
+        "value": mpix / dt, "unit": "Mpix/s", "cores": threads, "kind": "port",
+        "sample": f"the whole of C1 (BASELINE.json configs[0]): {cfg['w']}x{cfg['h']} max_dis={cfg['max_dis']} GRD single scale, 3 iterations, "
+                  f"reference order (serial raster sweep, serial window sum), OpenMP over the rows of init/refinement as the reference; "
+                  f"{dt:.1f} s, {taps / dt / 1e9:.3f} Gtap/s",
+        "seconds": dt,
+        "gpu_same_workload": {"value": mpix / gdt, "unit": "Mpix/s", "seconds": gdt, "note": "host buffers in, PCIe included"},
         "gpu_vs_cpu_bad0.5": float(np.mean([np.mean(d > 0.5) for d in diff])),
         "gpu_vs_cpu_bad2.0": float(np.mean([np.mean(d > 2.0) for d in diff])),
         "gpu_vs_cpu_max_abs_px": float(max(d.max() for d in diff)),
-        "value": cw * ch / dt / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
-        "sample": f"centred {cw}x{ch} crop of the same pair, max_dis={cfg['max_dis']}, {cfg['scale_num']} levels, "
-                  f"reference order (raster sweep, serial sum), OpenMP over rows of init/refinement as the reference; "
-                  f"{dt:.1f} s, {taps / dt / 1e9:.3f} Gtap/s (crop windows are border-clipped: optimistic for the CPU)",
-        "seconds": dt,
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C5 (crossscalepatchmatch_amd/synth.py)")
+    ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)
     ap.add_argument("--no-early-exit", action="store_true")
@@ -86,8 +106,8 @@ def main():
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU: libcspm_hip has no CPU fallback")
     backend = os.environ.get("CSPM_BENCH_BACKEND", "nccl")  # "gloo": only to exercise the N>1 control flow on a 1-GPU box
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
+    if args.gpus < 1 or args.in_flight < 1:
+        raise SystemExit("--gpus and --in-flight must be >= 1")
     if backend == "nccl" and ndev < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes only {ndev} GPU(s); one rank per GPU is required "
                          f"(set CSPM_BENCH_BACKEND=gloo to exercise the N>1 control flow with ranks sharing a GPU)")
@@ -123,84 +143,116 @@ def main():
     w, h = cfg["w"], cfg["h"]
     d_l = torch.from_numpy(l).to(dev)
     d_r = torch.from_numpy(r).to(dev)
-    d_out = [torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
-    ctx = cs.StereoContext(dev_index)
+    torch.cuda.synchronize()
     from crossscalepatchmatch_amd import capi
-    ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
+    nfl = max(1, min(args.in_flight, args.steps))
+    ctxs = [cs.StereoContext(dev_index) for _ in range(nfl)]  # each context owns a HIP stream
+    d_out = [[torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(nfl)]
+    for ctx in ctxs:
+        ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
     sched = cs.SCHED_RASTER if args.schedule == "raster" else cs.SCHED_REDBLACK
     pm_kw = dict(seed=12345, schedule=sched, rb_rounds=args.rb_rounds, rb_neighbours=4, early_exit=0 if args.no_early_exit else 1)
 
-    def step():
+    def step(k):
+        ctx, out = ctxs[k % nfl], d_out[k % nfl]  # everything below is enqueued on the context's stream, nothing waits
         ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
         (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
         ctx.patchmatch(3, **pm_kw)
         for v in (0, 1):
-            ctx.disparity_u8_device(v, cfg["dis_scale"], d_out[v].data_ptr())
+            ctx.disparity_u8_device(v, cfg["dis_scale"], out[v].data_ptr())
 
     def sync_all():
-        ctx.synchronize()
+        for ctx in ctxs:
+            ctx.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()
-    ctx.enable_timing(not args.no_kernel_timing)
-    ctx.reset_timing()
+    for k in range(args.warmup):
+        step(k)
+    for ctx in ctxs:
+        ctx.synchronize()
+        ctx.enable_timing(not args.no_kernel_timing)
+        ctx.reset_timing()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    timing = ctx.timing()
-    ctx.enable_timing(False)
+    timing = {}
+    for ctx in ctxs:
+        for k, v in ctx.timing().items():
+            acc = timing.setdefault(k, {"launches": 0, "ms": 0.0, "evals": 0})
+            for f in acc:
+                acc[f] += v[f]
+        ctx.enable_timing(False)
 
     if rank == 0:
+        ctx = ctxs[0]
         mpix = w * h * args.steps * world / dt / 1e6
-        taps_launch = 2 * ctx.taps_per_view_pass()  # one refinement launch evaluates every pixel of both views once
+        alg_taps = 2 * ctx.taps_per_view_pass()              # one evaluation of every pixel of both views (in-image window taps)
+        exe_taps = 2 * ctx.row_engine_taps_per_view_pass()   # lane-taps the row engine executes for it
         out = {
             "metric": "Mpix/s disparity (%s, use_cs=true)" % args.cc, "value": mpix, "unit": "Mpix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w}x{h} max_dis={cfg['max_dis']} GRD scale_num={cfg['scale_num']} "
                                    f"reg_lambda={cfg['reg_lambda']} wnd=35 iters=3 (BASELINE.json configs[2] when C3)",
-                       "cc_name": args.cc, "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule, "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds, "early_exit": not args.no_early_exit,
-                       "pairs_per_gpu": args.steps, "parallelism": f"{world} independent pair stream(s), one per GPU"},
+                       "cc_name": args.cc, "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule,
+                       "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds,
+                       "early_exit": not args.no_early_exit, "pairs_per_gpu": args.steps, "pairs_in_flight_per_gpu": nfl,
+                       "parallelism": f"{world} rank(s), one per GPU, {nfl} independent pair stream(s) each"},
         }
         ref = timing["refine"]
-        traffic = None  # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), committed
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.config == "C3" and args.cc == "GRD" and not args.volumes and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         if ref["launches"]:
+            # the dominant kernel: k_refine = all halving steps of one PlaneRefinement iteration (cs_patchmatch.cc:292-345)
             avg_s = ref["ms"] / ref["launches"] / 1e3
-            achieved = taps_launch * BYTES_PER_TAP / avg_s / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "kernel": "k_refine (plane cost evaluation, one PlaneRefinement halving step)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": taps_launch * BYTES_PER_TAP, "avg_launch_ms": avg_s * 1e3,
-                "launches": ref["launches"],
-                "note": "algorithmic bytes = in-image window taps x 19 B (SURVEY.md 8(d)); the tap stream is served on chip "
-                        "(measured HBM traffic is ~0.2 % of it), so frac vs the HBM peak exceeds 1: the binding resources are the "
-                        "CU L1 return path (TD ~97 % busy) and VALU issue, see DESIGN.md section 5; early exit skips taps but not "
-                        "algorithmic bytes",
+            steps_per_launch = ref["evals"] / ref["launches"] / (2 * w * h)
+            alg_bytes = alg_taps * steps_per_launch * BYTES_PER_TAP
+            roof = {
+                "kernel": "k_refine (row engine; one launch = the %d halving steps of one PlaneRefinement iteration)" % round(steps_per_launch),
+                "avg_launch_ms": avg_s * 1e3, "launches": ref["launches"],
+                "algorithmic_taps_per_launch": alg_taps * steps_per_launch, "executed_lane_taps_per_launch": exe_taps * steps_per_launch,
+                "executed_vs_algorithmic_taps": exe_taps / alg_taps,
+                "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBs": alg_bytes / avg_s / 1e9,
+                "taps_per_s": alg_taps * steps_per_launch / avg_s,
             }
+            pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
+            if pmc and args.config == "C3" and args.cc == "GRD" and not args.volumes:
+                winstr = pmc["valu_winstr_per_launch"]
+                peak = N_SIMD * pmc["shader_clock_ghz"] * 1e9 / VALU_CYCLES_PER_WINSTR
+                roof.update({
+                    "bound": "valu_issue", "achieved": winstr / avg_s / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+                    "frac": winstr / avg_s / peak,
+                    "traffic": pmc["hbm_bytes_per_launch"], "hbm_frac_of_peak": pmc["hbm_bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS,
+                    "lds_busy_frac_pmc": pmc["lds_busy_frac"], "valu_winstr_per_64_algorithmic_taps": winstr / (alg_taps * steps_per_launch / 64),
+                    "note": "The tap stream is served on chip (HBM traffic is a fraction of a percent of the algorithmic bytes), so the "
+                            "bound is not HBM.  bound = VALU issue: achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of "
+                            "the same command, profiles/r02_refine_pmc.json) / the launch time measured here; peak = 1024 SIMDs x shader "
+                            "clock / 4.1 cycles per wave-instruction (tools/ubench/valu_issue.hip).  The LDS (strips + tables) is the "
+                            "second resource, lds_busy_frac_pmc.  With two pairs in flight other kernels share the SIMDs with k_refine, "
+                            "so its launch time -- and frac -- is a lower bound on what the kernel reaches alone (--in-flight 1).",
+                })
+            else:
+                roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": None,
+                             "note": "instruction counts are committed for the headline workload only (C3, GRD, fused)"})
+            out["roofline"] = roof
         out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
-            out["cpu_baseline"] = cpu_baseline(cfg, l, r, dev_index)
+            out["cpu_baseline"] = cpu_baseline(dev_index)
         # sanity of the result that was timed (not part of the timed region)
         dl = ctx.disparity_f64(0)
         out["bad2_vs_gt_left"] = synth.bad_fraction(dl, gl, 2.0)
         print(json.dumps(out))
-    ctx.close()
+    for ctx in ctxs:
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "cspm_pm_default_params", "cspm_patchmatch", "cspm_pm_init", "cspm_pm_spatial", "cspm_pm_view", "cspm_pm_refine",
     "cspm_get_planes", "cspm_set_planes", "cspm_get_disparity_u8", "cspm_get_disparity_f64",
     "cspm_disparity_u8_device", "cspm_postprocess", "cspm_enable_timing", "cspm_reset_timing", "cspm_get_timing",
-    "cspm_taps_per_view_pass",
+    "cspm_taps_per_view_pass", "cspm_row_engine_taps_per_view_pass",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library():
         "cspm_reset_timing": (C.c_int, [vp]),
         "cspm_get_timing": (C.c_int, [vp, C.c_int, llp, dp, llp]),
         "cspm_taps_per_view_pass": (C.c_longlong, [vp]),
+        "cspm_row_engine_taps_per_view_pass": (C.c_longlong, [vp]),
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, (res, args) in sig.items():
@@ -306,3 +307,6 @@ class StereoContext:
 
     def taps_per_view_pass(self):
         return self.L.cspm_taps_per_view_pass(self.p)
+
+    def row_engine_taps_per_view_pass(self):
+        return self.L.cspm_row_engine_taps_per_view_pass(self.p)

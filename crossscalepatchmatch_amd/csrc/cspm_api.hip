@@ -51,6 +51,7 @@ enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2 };
 
 struct cspm_ctx {
   int device = 0, ncu = 256;
+  int sweep_wg_per_cu = 3;  // persistent sweep: workgroups launched per CU (tuning knob, env CSPM_SWEEP_WG)
   int refine_chunk = 64;  // PlaneRefinement halving steps per launch (tuning knob, env CSPM_REFINE_CHUNK)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
@@ -583,11 +584,11 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, sizeof(unsigned int), c->stream));  // the claim counter; ctrl[1] is sticky
     int ncu = c->ncu;
-    const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * 6);  // more than fit is harmless: unclaimed work is all a late workgroup needs
+    const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * c->sweep_wg_per_cu);  // more than fit is harmless: unclaimed work is all a late workgroup needs
     const unsigned waves = sweep_waves(c);
     {
       Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
-      LAUNCH_CS(k_spatial_sweep, dim3(grid), dim3(waves * kWave), 0, c->cost, pm, sw, inc);
+      LAUNCH_CS(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
     }
     c->sweep_pending = true;
   } else {
@@ -595,7 +596,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
       const long long items = 2LL * (ys_hi - ys_lo + 1);
       Timed t(c, CSPM_K_SPATIAL, items * 2);
-      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), 0, c->cost, pm, k, inc);
+      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), sweep_shared_bytes((int)sweep_waves(c)), c->cost, pm, k, inc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -669,6 +670,7 @@ int cspm_create(cspm_ctx **out, int device) {
   c->device = device;
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("CSPM_REFINE_CHUNK")) c->refine_chunk = std::max(1, atoi(e));
+  if (const char *e = getenv("CSPM_SWEEP_WG")) c->sweep_wg_per_cu = std::max(1, atoi(e));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
     return fail(nullptr, CSPM_ERR_HIP, hipGetErrorString(e));
@@ -1264,6 +1266,26 @@ long long cspm_taps_per_view_pass(const cspm_ctx *c) {
       sy += std::min(cy + cd.half, L.H - 1) - std::max(cy - cd.half, 0) + 1;
     }
     total += sx * sy;
+  }
+  return total;
+}
+
+// lane-taps the row engine EXECUTES for one evaluation of every pixel of one view: every lane of every 64-pixel wave walks
+// all window columns of the window rows that lie inside the image (columns outside the image are executed with weight 0,
+// the lanes past the end of an image row shadow its last pixel)
+long long cspm_row_engine_taps_per_view_pass(const cspm_ctx *c) {
+  if (!c || !c->cost_alloc) return 0;
+  long long total = 0;
+  const Cost &cd = c->cost;
+  const long long lanes_per_row = (long long)((c->W + kWave - 1) / kWave) * kWave;
+  for (int s = 0; s < cd.levels; ++s) {
+    const Level &L = cd.lv[s];
+    long long sy = 0;
+    for (int y = 0; y < c->H; ++y) {
+      const int cy = y >> s;
+      sy += std::min(cy + cd.half, L.H - 1) - std::max(cy - cd.half, 0) + 1;
+    }
+    total += sy * lanes_per_row * cd.n;
   }
   return total;
 }

@@ -258,16 +258,25 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // ------------------------------------------------------------------------------------------------
 constexpr int kSweepMaxWaves = 8;
 
+// views into the dynamic LDS of a sweep launch: sized by the waves actually launched (sweep_shared_bytes), so that a second
+// kernel -- another stereo pair's refinement -- still finds LDS on the CU
 struct SweepShared {
-  LutMem lut;
-  ChainScratch m[kSweepMaxWaves];
-  double lvl[2][CSPM_MAX_LEVELS];  // cross-scale: exact level sums
+  LutMem &lut;
+  double (*lvl)[CSPM_MAX_LEVELS];  // [2][levels]: cross-scale, exact level sums
+  ChainScratch *m;                 // one per wave (at least two: the single-scale path gathers both candidates there)
 };
+__host__ __device__ inline size_t sweep_shared_bytes(int waves) {
+  return sizeof(LutMem) + 2 * CSPM_MAX_LEVELS * sizeof(double) + (size_t)(waves < 2 ? 2 : waves) * sizeof(ChainScratch);
+}
+__device__ __forceinline__ SweepShared sweep_shared(unsigned char *smem) {
+  return SweepShared{*reinterpret_cast<LutMem *>(smem), reinterpret_cast<double (*)[CSPM_MAX_LEVELS]>(smem + sizeof(LutMem)),
+                     reinterpret_cast<ChainScratch *>(smem + sizeof(LutMem) + 2 * CSPM_MAX_LEVELS * sizeof(double))};
+}
 
 // Both candidate costs at pixel (x,y) of view v; every wave of the workgroup calls it.  `both` = the two candidates differ
 // (otherwise only c0 is evaluated and cost1 = cost0).  Results are valid in wave 0 after the call.
 template <bool CS, int SRC>
-__device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, SweepShared &sh, int v, int x, int y, const Cand &c0,
+__device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, const SweepShared &sh, int v, int x, int y, const Cand &c0,
                                                 const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
   if (CS) {
     // this wave's level `wave`: (cur_x, cur_y, cur_disp) after `wave` halvings (pre_cs_pc.cc:139-140,183-185)
@@ -344,7 +353,8 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
 // one launch per anti-diagonal k (sweep coordinates xs+ys == k, image x = inc>0 ? xs : W-1-xs); one workgroup per pixel
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd, Pm pm, int k, int inc) {
-  __shared__ SweepShared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const SweepShared sh = sweep_shared(smem);
   const Luts lut = load_luts(cd, sh.lut);
   const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
   const int cnt = ys_hi - ys_lo + 1;
@@ -430,7 +440,8 @@ __device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int
 
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spatial_sweep(Cost cd, Pm pm, Sweep sw, int inc) {
-  __shared__ SweepShared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const SweepShared sh = sweep_shared(smem);
   __shared__ double s_plane[2][6];
   __shared__ unsigned int s_item;
   __shared__ int s_ok;

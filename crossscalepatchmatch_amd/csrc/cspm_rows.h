@@ -405,30 +405,41 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   return tree.total(dy_hi + 1);
 }
 
-// Aggregated plane cost of 64 candidates, one per lane, each at its own centre column `x` (per lane, inside the image)
-// of row ctx.y of view VIEW.  (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param() -- per lane.  Returns the cost per
-// lane; lanes whose candidate is proven not to beat `thresh` (per lane) may return +inf instead (checked at level ends,
-// only when use_thresh; the wave leaves early once every lane is rejected).
-template <bool CS, int SRC, int VIEW>
-__device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut, const RowCtx &ctx, int x, double nx, double ny, double nz,
-                                                 double pa, double pb, double pc, double thresh, bool use_thresh) {
+// A candidate plane as a lane holds it between uses: Plane::norm() and Plane::param()
+struct RowPlane {
+  double nx, ny, nz, a, b, c;
+};
+
+// Aggregated plane cost of 64 candidates, one per lane, each at its own centre column (per lane, inside the image) of row
+// ctx.y of view VIEW.  Returns the cost per lane; lanes whose candidate is proven not to beat `thresh` (per lane) may return
+// +inf instead (checked at level ends, only when use_thresh; the wave leaves early once every lane is rejected).
+//
+// The candidate is NOT passed in: `gen(x)` produces it -- from the random stream and the planes in global memory -- and is
+// called again at every pyramid level.  Re-deriving six doubles costs ~10^2 instructions against the ~4*10^4 of a level,
+// and it keeps the normal, the parameters and whatever they were derived from out of the registers while the window loop
+// runs (the allocator would otherwise park them in scratch memory around every window row).  `x` is laundered through an
+// empty asm at each level so that the re-derivation is not hoisted back out of the level loop.
+template <bool CS, int SRC, int VIEW, class Gen>
+__device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut, const RowCtx &ctx, int x, Gen gen, double thresh,
+                                                 bool use_thresh) {
   double cost = 0.0;
   bool dead = false;
-  double cur_disp = pa * (double)x + pb * (double)ctx.y + pc;  // pre_cs_pc.cc:139-140
-  int cur_x = x, cur_y = ctx.y;
-  // Plane(org_norm, Point3d(cur_x,cur_y,cur_disp)).param() (:144-149): a and b depend on the normal only, so
-  // they are the same bits at every level; c is re-derived per level
-  double denom = fmax(fabs(nz), kDoubleEps);
-  if (nz < 0.0) denom = -denom;
-  const double a = CS ? -nx / denom : pa, b = CS ? -ny / denom : pb;
   const int levels = CS ? cd.levels : 1;
   for (int s = 0; s < levels; ++s) {
-    double c = pc;
+    int xs = x;
+    asm volatile("" : "+v"(xs));
+    const RowPlane p = gen(xs);
+    double a = p.a, b = p.b, c = p.c;
+    int cur_x = xs, cur_y = ctx.y;
     if (CS) {
-      double dot = nx * (double)cur_x;
-      dot += ny * (double)cur_y;
-      dot += nz * cur_disp;
-      c = dot / denom;
+      // Plane(org_norm, Point3d(cur_x,cur_y,cur_disp)).param() (:144-149) after s halvings (:183-185)
+      double cur_disp = p.a * (double)xs + p.b * (double)ctx.y + p.c;  // pre_cs_pc.cc:139-140
+      for (int k = 0; k < s; ++k) {
+        cur_y /= 2;
+        cur_x /= 2;
+        cur_disp /= 2.0;
+      }
+      plane_param(p.nx, p.ny, p.nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);
     }
     const double sc = level_rows<SRC, VIEW>(cd, lut, ctx, s, cur_x, cur_y, a, b, c);
     if (CS) cost += sc * cd.lv[s].wgt;  // :182
@@ -437,17 +448,14 @@ __device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut
       dead = dead | (cost >= thresh);
       if (__builtin_amdgcn_ballot_w64(!dead) == 0ull) break;  // every lane is rejected
     }
-    cur_y /= 2;  // :183-185
-    cur_x /= 2;
-    cur_disp /= 2.0;
   }
   return dead ? __builtin_inf() : cost;
 }
-template <bool CS, int SRC>
-__device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int view, int x, double nx, double ny,
-                                            double nz, double pa, double pb, double pc, double thresh, bool use_thresh) {
-  return view == 0 ? eval_rows_view<CS, SRC, 0>(cd, lut, ctx, x, nx, ny, nz, pa, pb, pc, thresh, use_thresh)
-                   : eval_rows_view<CS, SRC, 1>(cd, lut, ctx, x, nx, ny, nz, pa, pb, pc, thresh, use_thresh);
+template <bool CS, int SRC, class Gen>
+__device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int view, int x, Gen gen, double thresh,
+                                            bool use_thresh) {
+  return view == 0 ? eval_rows_view<CS, SRC, 0>(cd, lut, ctx, x, gen, thresh, use_thresh)
+                   : eval_rows_view<CS, SRC, 1>(cd, lut, ctx, x, gen, thresh, use_thresh);
 }
 
 // pixel run of this wave: item = (view, y, 64-pixel segment), XCD-banded.  Returns false past the end.
@@ -470,19 +478,9 @@ __device__ __forceinline__ bool row_item(int W, int H, int views, RowItem &it) {
 // ------------------------------------------------------------------------------------------------
 // CSPatchMatch::InitRandomPlane  (cs_patchmatch.cc:115-148)
 // ------------------------------------------------------------------------------------------------
-template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
-  const Luts lut = load_luts(cd, s_lut);
-  RowItem it;
-  if (!row_item(pm.W, pm.H, 2, it)) return;
-  const int lane = threadIdx.x & 63;
-  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
-  const bool live = it.x0 + lane < pm.W;
-  const int x = live ? it.x0 + lane : pm.W - 1;  // tail lanes shadow the last pixel
-  const long long i = (long long)it.y * pm.W + x;
-  const Rng rng(pm.seed, stream_id(0, 0, 0, it.v), pm.rng_row_shared ? (uint64_t)x : (uint64_t)i);
+__device__ __forceinline__ RowPlane init_plane(const Pm &pm, int v, int x, int y) {
+  const long long i = (long long)y * pm.W + x;
+  const Rng rng(pm.seed, stream_id(0, 0, 0, v), pm.rng_row_shared ? (uint64_t)x : (uint64_t)i);
   const double rand_dis = rng.uniform(0, kDoubleEps, (double)pm.max_dis);  // :134-135
   // direction: uniform on the sphere by rejection from the unit ball (DESIGN.md "RNG"); :137-140
   double r0 = 0.0, r1 = 0.0, r2 = 1.0, len = 1.0;
@@ -501,17 +499,56 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_init(Cost cd, Pm p
     if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;
   }
   const double inv = 1. / fmax(len, kDoubleEps);
-  const double nx = r0 * inv, ny = r1 * inv, nz = r2 * inv;
-  double a, b, c;
-  plane_param(nx, ny, nz, (double)x, (double)it.y, rand_dis, a, b, c);  // :141-142
-  const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, nx, ny, nz, a, b, c, kDoubleMax, false);  // :143-144
-  if (live) store_plane(pm.f[it.v], i, nx, ny, nz, a, b, c, cost);
+  RowPlane p;
+  p.nx = r0 * inv; p.ny = r1 * inv; p.nz = r2 * inv;
+  plane_param(p.nx, p.ny, p.nz, (double)x, (double)y, rand_dis, p.a, p.b, p.c);  // :141-142
+  return p;
+}
+
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
+  const Luts lut = load_luts(cd, s_lut);
+  RowItem it;
+  if (!row_item(pm.W, pm.H, 2, it)) return;
+  const int lane = threadIdx.x & 63;
+  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
+  const bool live = it.x0 + lane < pm.W;
+  const int x = live ? it.x0 + lane : pm.W - 1;  // tail lanes shadow the last pixel
+  auto gen = [&](int xs) { return init_plane(pm, it.v, xs, it.y); };
+  const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, gen, kDoubleMax, false);  // :143-144
+  if (live) {
+    const RowPlane p = gen(x);
+    store_plane(pm.f[it.v], (long long)it.y * pm.W + x, p.nx, p.ny, p.nz, p.a, p.b, p.c, cost);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// CSPatchMatch::PlaneRefinement  (cs_patchmatch.cc:292-345): ALL halving steps of one iteration in one launch.  A
-// pixel's steps depend only on that pixel's own earlier steps, so the lane keeps its plane in registers across them.
+// CSPatchMatch::PlaneRefinement  (cs_patchmatch.cc:292-345): several (by default all) halving steps of one iteration in
+// one launch.  A pixel's steps depend only on that pixel's own earlier steps; its current plane lives in the plane field
+// (global memory) and is re-read where it is needed.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ RowPlane refine_plane(const Pm &pm, int v, int x, int y, int iter, int step, double z_iter, double n_iter) {
+  const long long i = (long long)y * pm.W + x;
+  const Field &f = pm.f[v];
+  const double cnx = f.nx[i], cny = f.ny[i], cnz = f.nz[i], ca = f.a[i], cb = f.b[i], cc = f.c[i];
+  const Rng rng(pm.seed, stream_id(1, iter, step, v), pm.rng_row_shared ? (uint64_t)x : (uint64_t)i);
+  const double disturb_z = ca * (double)x + cb * (double)y + cc;             // :317-319
+  const double pz = disturb_z + rng.uniform(0, -z_iter, z_iter);             // :320-322
+  const double d0 = cnx + rng.uniform(1, -n_iter, n_iter);                   // :324-325
+  const double d1 = cny + rng.uniform(2, -n_iter, n_iter);
+  const double d2 = cnz + rng.uniform(3, -n_iter, n_iter);
+  double s = d0 * d0;
+  s += d1 * d1;
+  s += d2 * d2;
+  const double inv = 1. / fmax(__dsqrt_rn(s), kDoubleEps);                   // :326-328
+  RowPlane p;
+  p.nx = d0 * inv; p.ny = d1 * inv; p.nz = d2 * inv;
+  plane_param(p.nx, p.ny, p.nz, (double)x, (double)y, pz, p.a, p.b, p.c);    // :330
+  return p;
+}
+
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm pm, int iter, int first_step, int nsteps, double z_iter, double n_iter, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -525,34 +562,19 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm
   const int x = live ? it.x0 + lane : pm.W - 1;
   const long long i = (long long)it.y * pm.W + x;
   const Field &f = pm.f[it.v];
-  double cnx = f.nx[i], cny = f.ny[i], cnz = f.nz[i], ca = f.a[i], cb = f.b[i], cc = f.c[i];
   double cur_min = f.cost[i];
   const bool use_thresh = pm.use_thresh != 0 && *cd.early_ok != 0;
-  bool changed = false;
   for (int step = first_step; step < first_step + nsteps; ++step) {
-    const Rng rng(pm.seed, stream_id(1, iter, step, it.v), pm.rng_row_shared ? (uint64_t)x : (uint64_t)i);
-    const double disturb_z = ca * (double)x + cb * (double)it.y + cc;          // :317-319
-    const double pz = disturb_z + rng.uniform(0, -z_iter, z_iter);             // :320-322
-    const double d0 = cnx + rng.uniform(1, -n_iter, n_iter);                   // :324-325
-    const double d1 = cny + rng.uniform(2, -n_iter, n_iter);
-    const double d2 = cnz + rng.uniform(3, -n_iter, n_iter);
-    double s = d0 * d0;
-    s += d1 * d1;
-    s += d2 * d2;
-    const double inv = 1. / fmax(__dsqrt_rn(s), kDoubleEps);                   // :326-328
-    const double nx = d0 * inv, ny = d1 * inv, nz = d2 * inv;
-    double a, b, c;
-    plane_param(nx, ny, nz, (double)x, (double)it.y, pz, a, b, c);             // :330
-    const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, nx, ny, nz, a, b, c, cur_min, use_thresh);
+    auto gen = [&](int xs) { return refine_plane(pm, it.v, xs, it.y, iter, step, z_iter, n_iter); };
+    const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, gen, cur_min, use_thresh);
     if (cost < cur_min) {                                                      // :335-338
-      cnx = nx; cny = ny; cnz = nz; ca = a; cb = b; cc = c;
+      const RowPlane p = gen(x);  // before the store below changes what it is derived from
       cur_min = cost;
-      changed = true;
+      if (live) store_plane(f, i, p.nx, p.ny, p.nz, p.a, p.b, p.c, cost);
     }
     z_iter /= 2.0;  // :342-343
     n_iter /= 2.0;
   }
-  if (live && changed) store_plane(f, i, cnx, cny, cnz, ca, cb, cc, cur_min);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -560,8 +582,8 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm
 // Phase 1 (k_view_eval): every pixel (x,y) of the OTHER view proposes its plane to pixel (cor_x,y) of
 // view v and evaluates it there -- independent, because the pass only reads the other view's planes
 // and the candidates of a pass do not depend on each other.  Lane = source pixel; its evaluation centre
-// cor_x = x +- disparity moves with the disparity field: coherent where the field is smooth (the strip
-// still covers the wave), anything else falls back to global gathers for that level.
+// cor_x = x +- disparity moves with the disparity field: coherent where the field is smooth (the strips
+// still cover the wave), anything else falls back to global gathers for that level.
 // Phase 2 (k_view_resolve): the serial loop keeps, per target pixel, the candidate with the smallest
 // cost that is < the pixel's current cost, the earliest in traversal order among equal costs.  One
 // workgroup per row (cor_x stays in row y) reproduces exactly that with LDS atomics.
@@ -571,6 +593,26 @@ struct ViewCand {
   double *c;    // candidate param c (a, b follow from the source normal)
   int *cx;      // target column
 };
+
+// the proposal of source pixel (x,y) of view 1-v: target column (may be outside the image) and the plane anchored there
+struct ViewProposal {
+  RowPlane p;
+  int cor_x;
+};
+__device__ __forceinline__ ViewProposal view_proposal(const Pm &pm, int v, int x, int y) {
+  const long long i = (long long)y * pm.W + x;
+  const Field &src = pm.f[1 - v];
+  ViewProposal q;
+  q.p.nx = src.nx[i]; q.p.ny = src.ny[i]; q.p.nz = src.nz[i];
+  double disp = src.a[i] * (double)x + src.b[i] * (double)y + src.c[i];  // :245-246
+  if (disp < 0.0) disp = 0.0;                                             // :247-252
+  if (disp >= (double)pm.max_dis) disp = (double)pm.max_dis - 1.0;
+  const int r = round2int(disp);
+  q.cor_x = handle_border(v == 0 ? x + r : x - r, pm.W);                  // :255-261
+  const bool inside = q.cor_x >= 0 && q.cor_x < pm.W;
+  plane_param(q.p.nx, q.p.ny, q.p.nz, (double)(inside ? q.cor_x : x), (double)y, disp, q.p.a, q.p.b, q.p.c);  // :263-265
+  return q;
+}
 
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap, int ocap) {
@@ -585,26 +627,19 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_view_eval(Cost cd,
   const int x = live ? it.x0 + lane : pm.W - 1;
   const int y = it.y;
   const long long i = (long long)y * pm.W + x;
-  const Field &src = pm.f[1 - v];
-  const Field &dst = pm.f[v];
-  const double nx = src.nx[i], ny = src.ny[i], nz = src.nz[i];
-  double disp = src.a[i] * (double)x + src.b[i] * (double)y + src.c[i];  // :245-246
-  if (disp < 0.0) disp = 0.0;                                             // :247-252
-  if (disp >= (double)pm.max_dis) disp = (double)pm.max_dis - 1.0;
-  const int r = round2int(disp);
-  const int cor_x = handle_border(v == 0 ? x + r : x - r, pm.W);          // :255-261
-  const bool inside = cor_x >= 0 && cor_x < pm.W;
-  const int ex = inside ? cor_x : x;
-  double a, b, c;
-  plane_param(nx, ny, nz, (double)ex, (double)y, disp, a, b, c);          // :263-265
-  const double thr = dst.cost[(long long)y * pm.W + ex];
+  const ViewProposal q0 = view_proposal(pm, v, x, y);
+  const bool inside = q0.cor_x >= 0 && q0.cor_x < pm.W;
+  const int ex = inside ? q0.cor_x : x;  // lanes without a target evaluate in place and discard the result
   const bool use_thresh = pm.use_thresh != 0 && *cd.early_ok != 0;
-  double cost = eval_rows<CS, SRC>(cd, lut, ctx, v, ex, nx, ny, nz, a, b, c, use_thresh ? thr : kDoubleMax, use_thresh);  // :266-267
+  const double thr = use_thresh ? pm.f[v].cost[(long long)y * pm.W + ex] : kDoubleMax;
+  const int dx = ex - x;  // the generator is handed the (laundered) evaluation column; the source column is dx to its left
+  auto gen = [&](int exs) { return view_proposal(pm, v, exs - dx, y).p; };
+  double cost = eval_rows<CS, SRC>(cd, lut, ctx, v, ex, gen, thr, use_thresh);  // :266-267
   if (!inside) cost = __builtin_inf();
   if (live) {
     vc.cost[i] = cost;
-    vc.c[i] = c;
-    vc.cx[i] = cor_x;
+    vc.c[i] = view_proposal(pm, v, x, y).p.c;
+    vc.cx[i] = q0.cor_x;
   }
 }
 

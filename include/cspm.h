@@ -34,7 +34,7 @@ typedef struct cspm_ctx cspm_ctx;
 
 /* SpatialPropagation schedule (cs_patchmatch.cc:163-216) */
 #define CSPM_SCHED_RASTER 0   /* reference order: in-place raster sweep, run as an anti-diagonal wavefront */
-#define CSPM_SCHED_REDBLACK 1 /* checkerboard half-steps (fast path) */
+#define CSPM_SCHED_REDBLACK 1 /* checkerboard half-steps (option: fewer dependencies, clearly lower quality) */
 
 /* rng flags */
 #define CSPM_RNG_PER_PIXEL 0
@@ -62,7 +62,9 @@ int cspm_synchronize(cspm_ctx *ctx);
 /* ---- images: PreSSPC/PreCSPC/CSPatchMatch constructors' (l_img, r_img) ----------------------
  * pre_ss_pc.cc:12-30, pre_cs_pc.cc:12-30, cs_patchmatch.cc:3-11.  stride in bytes (>= 3*w). */
 int cspm_set_images(cspm_ctx *ctx, const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h, size_t stride);
-/* same, from device memory already resident in HBM (bench / batch driver) */
+/* same, from device memory already resident in HBM (bench / batch driver).  The copy kernels are enqueued on the ctx
+ * stream and nothing waits for the host: the caller orders the PRODUCER of the buffers before this call (same stream,
+ * an event the ctx stream waits on, or a synchronisation) and keeps them alive until the stream has passed the call. */
 int cspm_set_images_device(cspm_ctx *ctx, const void *d_l_bgr, const void *d_r_bgr, int w, int h, size_t stride);
 
 /* ---- plane cost construction ------------------------------------------------------------------
@@ -110,13 +112,16 @@ int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
 
 /* ---- IPlaneCost::GetPlaneCost, batched (plane_cost/i_plane_cost.h:28-33) ----------------------
  * xy: 2 ints per item; plane: 6 doubles per item = Plane::norm() then Plane::param().
- * Summation order is the device order (DESIGN.md "SLOT256"); differs from the reference's serial
- * sum only by rounding. */
+ * Summation order is the device order ("ROWTREE7": the same terms as the reference's
+ * serial sum, other association; differs by rounding only, <= 1e-12 relative). */
 int cspm_plane_cost_batch(cspm_ctx *ctx, int view, int n, const int *xy, const double *norm_param, double *cost_out);
 
 /* ---- CSPatchMatch ------------------------------------------------------------------------------
  * cspm_patchmatch = CSPatchMatch::PatchMatch(iter_num, plane_cost, false) without PlaneToDisp
- * (cs_patchmatch.cc:51-102); max_dis / images are those of the ctx. */
+ * (cs_patchmatch.cc:51-102); max_dis / images are those of the ctx.  params == NULL: cspm_pm_default_params (raster
+ * schedule).  ASYNCHRONOUS: the kernels are enqueued on the ctx stream and the call returns; an error inside the run
+ * (a raster sweep whose inter-workgroup hand-off timed out) is reported by the next call that synchronises with the
+ * host: cspm_synchronize or any cspm_get_* / cspm_postprocess. */
 int cspm_pm_default_params(cspm_pm_params *p);
 int cspm_patchmatch(cspm_ctx *ctx, int iter_num, const cspm_pm_params *p);
 /* single phases (cs_patchmatch.cc:115-148, 163-216, 229-277, 292-345) for phase-by-phase parity */
@@ -150,6 +155,9 @@ int cspm_reset_timing(cspm_ctx *ctx);
 int cspm_get_timing(cspm_ctx *ctx, int kclass, long long *launches, double *total_ms, long long *evals);
 /* exact in-image window taps of ONE evaluation of every pixel of one view (sum over pixels, levels) */
 long long cspm_taps_per_view_pass(const cspm_ctx *ctx);
+/* lane-taps the row engine executes for the same pass (masked window columns and tail lanes included): the denominator of
+ * "executed vs algorithmic taps" */
+long long cspm_row_engine_taps_per_view_pass(const cspm_ctx *ctx);
 
 #ifdef __cplusplus
 }

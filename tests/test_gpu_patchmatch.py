@@ -178,6 +178,57 @@ def test_census_pipeline_bit_exact(gpu_ctx, mid_pair, scale_num, lam, volumes):
     np.testing.assert_array_equal(r, pm.dis(1))
 
 
+@pytest.mark.parametrize("wnd", [1, 3, 9, 13, 41, 45])
+@pytest.mark.parametrize("name,scale_num,lam", MODES)
+def test_window_sizes_through_both_engines(gpu_ctx, odd_pair, name, scale_num, lam, wnd):
+    """wnd_size is a constructor argument (pre_ss_pc.h:20-22); 35 = 5 x 7 is only main.cc's constant.  Windows that are not a
+    multiple of 7 exercise the row engine's tail groups, windows wider / taller than the coarse levels its column mask and
+    skipped rows, 45 the largest chain-engine layout (5 passes)."""
+    gpu_ctx.set_images(odd_pair["l"], odd_pair["r"])
+    gpu_ctx.build_cost_grd(odd_pair["max_dis"], wnd, scale_num, lam)
+    pc = po.PlaneCost(odd_pair["l"], odd_pair["r"], odd_pair["max_dis"], wnd, scale_num, lam)
+    pm = po.PatchMatch(odd_pair["l"], odd_pair["r"], odd_pair["max_dis"], 4)
+    pm.run(2, pc, False, seed=wnd, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.patchmatch(2, seed=wnd, schedule=po.SCHED_RASTER)
+    _assert_state_equal(gpu_ctx, pm, f"wnd {wnd}")
+
+
+@pytest.mark.parametrize("cc", ["GRD", "CEN"])
+def test_disparity_range_wider_than_the_lds_strip(gpu_ctx, cc):
+    """max_dis = 400 on a 150-pixel-wide pair: the other view's row window (64 centres + window + disparity range) exceeds
+    the strip a wave can stage (384 slots), so level 0 of the row engine reads both views from global memory, and view
+    propagation wraps around the image border (HandleBorder); coarser levels are staged again."""
+    from crossscalepatchmatch_amd import synth
+    l, r, _, _ = synth.make_pair(150, 24, 40, regions=3, seed=77)
+    D = 400
+    gpu_ctx.set_images(l, r)
+    (gpu_ctx.build_cost_grd if cc == "GRD" else gpu_ctx.build_cost_cen)(D, 35, 3, 0.3)
+    pc = po.PlaneCost(l, r, D, 35, 3, 0.3, cc=cc)
+    pm = po.PatchMatch(l, r, D, 1)
+    pm.run(1, pc, False, seed=8, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.patchmatch(1, seed=8, schedule=po.SCHED_RASTER)
+    _assert_state_equal(gpu_ctx, pm, "wide disparity range")
+
+
+def test_set_planes_makes_the_sweep_distrust_stored_costs(gpu_ctx, small_pair):
+    """The raster sweep skips a neighbour whose plane is bitwise the pixel's own -- valid only while every stored cost is the
+    cost of the stored plane.  cspm_set_planes can break that (here: all planes equal, all costs huge); the sweep must then
+    evaluate, as the reference does, and lower every cost."""
+    pc, pm = _setup(gpu_ctx, small_pair, 5, 0.3)
+    h, w = small_pair["h"], small_pair["w"]
+    for v in (0, 1):
+        P = pm.planes(v)
+        P[..., 0:2] = 0.0; P[..., 2] = 1.0
+        P[..., 3] = np.arange(w)[None, :]; P[..., 4] = np.arange(h)[:, None]; P[..., 5] = 6.5
+        P[..., 6:8] = 0.0; P[..., 8] = 6.5
+        pm.min_cost(v)[...] = 1e9
+        gpu_ctx.set_planes(v, np.concatenate([P[..., 0:3], P[..., 6:9]], -1), pm.min_cost(v))
+    pm.spatial(0, pc, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.pm_spatial(0, schedule=po.SCHED_RASTER)
+    _assert_state_equal(gpu_ctx, pm, "sweep after set_planes")
+    assert pm.min_cost(0)[5, 5] < 1e8
+
+
 @pytest.mark.parametrize("w,h,D", [(1, 1, 2), (2, 1, 2), (1, 7, 3), (9, 2, 4), (5, 40, 4), (37, 3, 6), (20, 20, 25)])
 def test_degenerate_image_sizes(gpu_ctx, w, h, D):
     """Ragged / tiny inputs: single pixels, single rows and columns, windows larger than the image, max_dis > width

@@ -1,0 +1,5 @@
+#!/bin/bash
+# throughput vs sweep workgroups per CU and pairs in flight (GPU box)
+for wg in 6 4 3 2; do for n in 1 2 3 4; do
+  CSPM_SWEEP_WG=$wg python bench.py --no-cpu-baseline --in-flight $n --steps 8 --warmup 4 2>/dev/null | python tools/bench_brief.py "sweep_wg=$wg"
+done; done
