@@ -543,7 +543,7 @@ int do_init(cspm_ctx *c, const cspm_pm_params *p) {
 
 // waves of a sweep workgroup: cross-scale -> one per pyramid level; single-scale -> one per chain pass of a full window
 inline unsigned sweep_waves(const cspm_ctx *c) {
-  return c->cost.cs ? (unsigned)c->cost.levels : (unsigned)((c->cost.n + kChainRows - 1) / kChainRows);
+  return c->cost.cs ? (unsigned)(c->cost.levels * kSweepWpl) : (unsigned)((c->cost.n + kChainRows - 1) / kChainRows);
 }
 
 int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {

@@ -256,7 +256,11 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // every tap is computed once).  Work split: cross-scale -> one wave per pyramid level; single-scale -> one wave per
 // chain pass.  No early exit: both candidate costs are needed in full when accepted.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSweepMaxWaves = 8;
+#ifndef CSPM_SWEEP_WPL
+#define CSPM_SWEEP_WPL 1
+#endif
+constexpr int kSweepWpl = CSPM_SWEEP_WPL;  // waves per pyramid level in a cross-scale sweep workgroup
+constexpr int kSweepMaxWaves = 16;
 
 // views into the dynamic LDS of a sweep launch: sized by the waves actually launched (sweep_shared_bytes), so that a second
 // kernel -- another stereo pair's refinement -- still finds LDS on the CU
@@ -279,39 +283,63 @@ template <bool CS, int SRC>
 __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, const SweepShared &sh, int v, int x, int y, const Cand &c0,
                                                 const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
   if (CS) {
-    // this wave's level `wave`: (cur_x, cur_y, cur_disp) after `wave` halvings (pre_cs_pc.cc:139-140,183-185)
-    if (wave < cd.levels) {
-      double d0 = c0.a * (double)x + c0.b * (double)y + c0.c, d1 = c1.a * (double)x + c1.b * (double)y + c1.c;
-      int cur_x = x, cur_y = y;
-      for (int s = 0; s < wave; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
-      const ChainLevel A = make_chain_level<SRC>(cd, wave, v, cur_x, cur_y);
-      ChainScratch &m = sh.m[wave];
+    // kSweepWpl waves per pyramid level share its chain passes (a sweep pixel is latency-bound: its evaluation is on the
+    // critical path of the whole sweep).  Level of this wave: (cur_x, cur_y, cur_disp) after `level` halvings
+    // (pre_cs_pc.cc:139-140,183-185).
+    const int level = wave / kSweepWpl, part_of = wave - level * kSweepWpl;
+    double d0 = c0.a * (double)x + c0.b * (double)y + c0.c, d1 = c1.a * (double)x + c1.b * (double)y + c1.c;
+    int cur_x = x, cur_y = y;
+    for (int s = 0; s < level; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
+    const ChainLevel A = make_chain_level<SRC>(cd, level < cd.levels ? level : 0, v, cur_x, cur_y);
+    ChainScratch &m = sh.m[wave];
+    double *part0 = sh.m[level * kSweepWpl].part, *part1 = sh.m[level * kSweepWpl + (kSweepWpl > 1 ? 1 : 0)].part;
+    if (level < cd.levels) {
       double pa, pb, pc;
       plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pa, pb, pc);  // :144-149
       fill_tabs(m, 0, A, pa, pb, pc, lane);
-      double s0, s1;
       if (both) {
         plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
         fill_tabs(m, 1, A, pa, pb, pc, lane);
         wave_lds_fence();
         double S[2][kMaxPasses];
-        chain_passes<SRC, 2>(cd, A, lut, m, lane, 0, 1, S);
-        store_parts<2>(m.part, S, 0, lane, 0, 1, A.passes);
-        wave_lds_fence();
-        s0 = finish_level(A, m.part, lane);
-        wave_lds_fence();
-        store_parts<2>(m.part, S, 1, lane, 0, 1, A.passes);
-        wave_lds_fence();
-        s1 = finish_level(A, m.part, lane);
+        chain_passes<SRC, 2>(cd, A, lut, m, lane, part_of, kSweepWpl, S);
+        if (kSweepWpl > 1) {
+          store_parts<2>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
+          store_parts<2>(part1, S, 1, lane, part_of, kSweepWpl, A.passes);
+        } else {  // one wave per level: its own buffer serves both candidates in turn
+          store_parts<2>(part0, S, 0, lane, 0, 1, A.passes);
+          wave_lds_fence();
+          const double s0 = finish_level(A, part0, lane);
+          wave_lds_fence();
+          store_parts<2>(part0, S, 1, lane, 0, 1, A.passes);
+          wave_lds_fence();
+          const double s1 = finish_level(A, part0, lane);
+          if (lane == 0) { sh.lvl[0][level] = s0; sh.lvl[1][level] = s1; }
+        }
       } else {
         wave_lds_fence();
         double S[1][kMaxPasses];
-        chain_passes<SRC, 1>(cd, A, lut, m, lane, 0, 1, S);
-        store_parts<1>(m.part, S, 0, lane, 0, 1, A.passes);
-        wave_lds_fence();
-        s0 = s1 = finish_level(A, m.part, lane);
+        chain_passes<SRC, 1>(cd, A, lut, m, lane, part_of, kSweepWpl, S);
+        store_parts<1>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
+        if (kSweepWpl == 1) {
+          wave_lds_fence();
+          const double s0 = finish_level(A, part0, lane);
+          if (lane == 0) { sh.lvl[0][level] = s0; sh.lvl[1][level] = s0; }
+        }
       }
-      if (lane == 0) { sh.lvl[0][wave] = s0; sh.lvl[1][wave] = s1; }
+    }
+    if (kSweepWpl > 1) {
+      __syncthreads();  // the chain sums of every level are complete
+      if (level < cd.levels) {
+        // candidate 0 is finished by the level's first wave, candidate 1 by its second
+        if (part_of == 0) {
+          const double s0 = finish_level(A, part0, lane);
+          if (lane == 0) { sh.lvl[0][level] = s0; if (!both) sh.lvl[1][level] = s0; }
+        } else if (part_of == 1 && both) {
+          const double s1 = finish_level(A, part1, lane);
+          if (lane == 0) sh.lvl[1][level] = s1;
+        }
+      }
     }
     __syncthreads();
     cost0 = cost1 = 0.0;
