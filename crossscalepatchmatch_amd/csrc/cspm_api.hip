@@ -1290,4 +1290,14 @@ long long cspm_row_engine_taps_per_view_pass(const cspm_ctx *c) {
   return total;
 }
 
+#ifdef CSPM_COUNT_ALIVE
+// debug build only: lanes alive after each pyramid level / lanes evaluated at each level, summed over every row-engine launch
+int cspm_debug_alive(unsigned long long *out16, int reset) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cspm::g_alive), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_alive), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  return CSPM_OK;
+}
+#endif
+
 }  // extern "C"

@@ -405,6 +405,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   return tree.total(dy_hi + 1);
 }
 
+#ifdef CSPM_COUNT_ALIVE
+__device__ unsigned long long g_alive[16];  // debug: lanes still alive after level s, lanes evaluated at level s
+#endif
 // A candidate plane as a lane holds it between uses: Plane::norm() and Plane::param()
 struct RowPlane {
   double nx, ny, nz, a, b, c;
@@ -446,6 +449,13 @@ __device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut
     else cost = sc;
     if (use_thresh) {
       dead = dead | (cost >= thresh);
+#ifdef CSPM_COUNT_ALIVE
+      {
+        const unsigned long long alive_mask = __builtin_amdgcn_ballot_w64(!dead);
+        if (ctx.lane == 0) atomicAdd(&g_alive[s], (unsigned long long)__popcll(alive_mask));
+        if (ctx.lane == 0) atomicAdd(&g_alive[8 + s], 64ull);
+      }
+#endif
       if (__builtin_amdgcn_ballot_w64(!dead) == 0ull) break;  // every lane is rejected
     }
   }

@@ -1,0 +1,26 @@
+#!/bin/bash
+# The evidence set of a round, on the GPU box: tools/profile_round.sh <tag>  ->  gpurun_out/<tag>/
+set -u
+TAG=$1
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+# 1. the default bench line (three pairs in flight, CPU baseline) and the one-pair-at-a-time line
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_inflight1.json 2> /dev/null
+# 2. kernel trace of the one-pair-at-a-time command (average launch durations must agree with its hipEvent figures)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_traced.json 2> /dev/null
+# 3. HIP API trace: no allocator call in a steady-state step
+rocprofv3 --hip-trace --stats --output-format csv -d $O/hip -o h -- python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+# 4. PMC passes of the same command
+tools/pmc_run.sh $TAG refine,sweep,view_eval,init -- python $R/bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python tools/pmc_to_json.py gpurun_out/$TAG k_refine gpurun_out/$TAG/refine_pmc.json "bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline: C3, (1 warm-up + 1 timed) pairs x 3 iterations = 6 launches of k_refine<true,1>" > /dev/null
+python tools/pmc_to_json.py gpurun_out/$TAG k_spatial_sweep gpurun_out/$TAG/sweep_pmc.json "same command: 6 launches of k_spatial_sweep<true,1>" > /dev/null
+./tools/ubench/valu_issue > $O/valu_issue.txt 2>&1
+python tools/bench_brief.py default < $O/bench_default.json
+python tools/bench_brief.py inflight1 < $O/bench_inflight1.json
+head -4 $O/trace/t_kernel_stats.csv | cut -c1-150
+grep -i "malloc\|free" $O/hip/h_hip_api_stats.csv | cut -c1-150
