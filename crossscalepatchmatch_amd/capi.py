@@ -20,7 +20,7 @@ OPT_RASTER_LAUNCHES = 2
 # every symbol include/cspm.h declares
 SYMBOLS = [
     "cspm_device_count", "cspm_create", "cspm_destroy", "cspm_last_error", "cspm_set_stream", "cspm_synchronize",
-    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_build_cost_cen", "cspm_cen_build_cv_host", "cspm_set_option", "cspm_begin_cost", "cspm_upload_cost_slab",
+    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_build_cost_cen", "cspm_build_cost_img", "cspm_cen_build_cv_host", "cspm_set_option", "cspm_begin_cost", "cspm_upload_cost_slab",
     "cspm_finish_cost", "cspm_get_levels", "cspm_get_level_dims", "cspm_get_level_image", "cspm_get_cost_slab",
     "cspm_get_max_cost", "cspm_get_scale_weights", "cspm_grd_build_cv_host", "cspm_plane_cost_batch",
     "cspm_pm_default_params", "cspm_patchmatch", "cspm_pm_init", "cspm_pm_spatial", "cspm_pm_view", "cspm_pm_refine",
@@ -79,6 +79,7 @@ def load_library():
         "cspm_build_cost_grd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_set_option": (C.c_int, [vp, C.c_int, C.c_longlong]),
         "cspm_build_cost_cen": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
+        "cspm_build_cost_img": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_cen_build_cv_host": (C.c_int, [C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
         "cspm_begin_cost": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_upload_cost_slab": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, C.c_size_t]),
@@ -180,6 +181,10 @@ class StereoContext:
     def build_cost_cen(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False):
         self.set_option(OPT_GRD_VOLUMES, int(volumes))
         self._chk(self.L.cspm_build_cost_cen(self.p, max_dis, wnd_size, scale_num, reg_lambda))
+
+    def build_cost_img(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):
+        """GrdPC (scale_num=0) / CSPC: the volume-free plane costs (plane_cost/grd_pc.cc, cspc.cc)"""
+        self._chk(self.L.cspm_build_cost_img(self.p, max_dis, wnd_size, scale_num, reg_lambda))
 
     def begin_cost(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0):
         self._chk(self.L.cspm_begin_cost(self.p, max_dis, wnd_size, scale_num, reg_lambda))

@@ -47,7 +47,7 @@ struct CostKey {
     return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind;
   }
 };
-enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2 };
+enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2, kKindImg = 3 };
 
 struct cspm_ctx {
   int device = 0, ncu = 256;
@@ -74,6 +74,7 @@ struct cspm_ctx {
   double *d_lut = nullptr, *d_lut_a = nullptr, *d_maxcost = nullptr;
   bool is_grd = false;           // cost built by cspm_build_cost_grd (gradients present)
   bool is_cen = false;           // cost built by cspm_build_cost_cen (census codes present)
+  bool is_img = false;           // cost built by cspm_build_cost_img (GrdPC / CSPC: no cells, no volumes)
   const uint32_t *cen_code[2][CSPM_MAX_LEVELS] = {{nullptr}};
   long long opt_grd_volumes = 0; // CSPM_OPT_GRD_VOLUMES
   unsigned long long *d_maxkeys = nullptr;
@@ -365,6 +366,10 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
           double *g;
           if ((rc = dalloc(c, &g, ppx, &c->cost_allocs))) return rc;
           L.grd[v] = g;
+        } else if (kind == kKindImg) {
+          uint8_t *gray;
+          if ((rc = dalloc(c, &gray, px, &c->cost_allocs))) return rc;
+          c->cen_gray[v][s] = gray;
         } else if (kind == kKindCen) {
           uint8_t *gray;
           uint32_t *code;
@@ -413,18 +418,19 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   cd.fused = kSrcVolume;
   c->is_grd = false;
   c->is_cen = false;
+  c->is_img = false;
   return CSPM_OK;
 }
 
 // max_cost of every level/view from the reduced keys and the early-exit licence, all on the device: no host round trip.
 // The early-exit proof (cspm_kernels.h level_cost) needs every term of the sum to be >= 0: scale weights (checked here),
 // cell costs (GRD and census cells are >= 0 by construction; an uploaded volume is checked through its reduced MIN).
-int finish_cost(cspm_ctx *c, bool check_min) {
+int finish_cost(cspm_ctx *c, bool check_min, double floor_val = -1.0) {
   Cost &cd = c->cost;
   int wgt_ok = 1;
   for (int s = 0; s < cd.levels; ++s)
     if (!(c->scale_wgt[s] >= 0.0)) wgt_ok = 0;
-  hipLaunchKernelGGL(k_finish_cost, dim3(1), dim3(64), 0, c->stream, c->d_maxkeys, c->d_maxcost, 2 * CSPM_MAX_LEVELS, cd.levels, -1.0,
+  hipLaunchKernelGGL(k_finish_cost, dim3(1), dim3(64), 0, c->stream, c->d_maxkeys, c->d_maxcost, 2 * CSPM_MAX_LEVELS, cd.levels, floor_val,
                      wgt_ok, check_min ? 1 : 0, c->d_early_ok);
   HIPCHK(c, hipGetLastError());
   c->cost_ready = true;
@@ -521,10 +527,12 @@ int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
     if (c->cost.cs) {                                                                                             \
       if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<true, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);          \
       else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<true, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);     \
+      else if (src_ == kSrcImg) hipLaunchKernelGGL((kern<true, kSrcImg>), grid, block, shmem, c->stream, __VA_ARGS__);     \
       else hipLaunchKernelGGL((kern<true, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                       \
     } else {                                                                                                      \
       if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<false, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);         \
       else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<false, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);    \
+      else if (src_ == kSrcImg) hipLaunchKernelGGL((kern<false, kSrcImg>), grid, block, shmem, c->stream, __VA_ARGS__);    \
       else hipLaunchKernelGGL((kern<false, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                      \
     }                                                                                                             \
   } while (0)
@@ -845,6 +853,34 @@ int cspm_build_cost_cen(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   return finish_cost(c, false);
 }
 
+// `new GrdPC(l, r, max_dis, wnd)` (scale_num == 0; plane_cost/grd_pc.cc:11-66) / `new CSPC(l, r, max_dis, wnd, scale_num,
+// reg_lambda)` (cspc.cc:11-93): pyramid, 8U gray and its x-gradient per level; no volumes, no CCMethod.  max_cost_ has no
+// counterpart in these classes: the "impossible disparity" cost is a constant (grd_pc.cc:131-132, cspc.cc:150-152).
+int cspm_build_cost_img(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda) {
+  if (!c) return CSPM_ERR_ARG;
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, false, kKindImg);
+  if (rc) return rc;
+  Cost &cd = c->cost;
+  for (int s = 0; s < cd.levels; ++s) {
+    Level &L = cd.lv[s];
+    const long long px = (long long)L.W * L.H, ppx = (long long)L.Wp * L.H;
+    for (int v = 0; v < 2; ++v) {
+      uint8_t *gray = c->cen_gray[v][s];
+      Timed t(c, CSPM_K_GRD, 0);
+      hipLaunchKernelGGL(k_gray8_u8, dim3(ew_grid(px)), dim3(256), 0, c->stream, L.pix[v], L.W, L.H, L.Wp, L.pad, gray);
+      hipLaunchKernelGGL(k_make_aos_img, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const uint8_t *)gray, L.W, L.H, L.Wp, L.pad,
+                         (PixG *)L.px[v]);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  cd.fused = kSrcImg;
+  c->is_img = true;
+  const double alpha = 0.1, tau_clr = 10.0, tau_grd = 2.0;
+  return finish_cost(c, false, alpha * tau_clr + (1 - alpha) * tau_grd);
+}
+
 // CenCC::buildCV / buildRightCV on host buffers (cc_method.h:31-32, cc/cen_cc.cc:4-137)
 int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, int right_view, double *vol_out) {
   if (!l_rgb || !r_rgb || !vol_out || w < 1 || h < 1 || maxDis < 1) return fail(nullptr, CSPM_ERR_ARG, "bad arguments");
@@ -896,7 +932,7 @@ int cspm_begin_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, doubl
 
 int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double *slab, size_t stride_elems) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc || c->is_grd || c->is_cen || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || c->is_cen || c->is_img || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   if (view < 0 || view > 1 || level < 0 || level >= c->cost.levels || !slab) return fail(c, CSPM_ERR_ARG, "bad view/level/slab");
   const Level &L = c->cost.lv[level];
   if (d < 0 || d > L.D || stride_elems < (size_t)L.W) return fail(c, CSPM_ERR_ARG, "bad slab index or stride");
@@ -912,7 +948,7 @@ int cspm_upload_cost_slab(cspm_ctx *c, int view, int level, int d, const double 
 
 int cspm_finish_cost(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
-  if (!c->cost_alloc || c->is_grd || c->is_cen || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
+  if (!c->cost_alloc || c->is_grd || c->is_cen || c->is_img || !c->cost.lv[0].vol[0]) return fail(c, CSPM_ERR_STATE, "cspm_begin_cost first");
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   HIPCHK(c, hipMemsetAsync(c->d_maxkeys, 0, sizeof(unsigned long long) * 2 * CSPM_MAX_LEVELS, c->stream));
@@ -969,6 +1005,7 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return CSPM_OK;
   }
+  if (c->is_img) return fail(c, CSPM_ERR_STATE, "GrdPC / CSPC have no cost volumes");
   // fused cost: materialise the requested slab with the volume kernel
   double *tmp;
   HIPCHK(c, hipMalloc((void **)&tmp, sizeof(double) * px));

@@ -38,6 +38,7 @@ struct ChainLevel {
   double maxc;
   const char *px, *opx;  // own / other view elements
   int dirE;              // byte step towards larger disparity in the other view: -E (left view) or +E
+  double sgn;            // 2*view-1 as a double (GrdPC / CSPC: other_x = q_x + (2*view-1)*q_disp)
   const double *vol;
   size_t slab;
   uint32_t Ip;
@@ -65,6 +66,7 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
     A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
     A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
   }
+  A.sgn = view == 0 ? -1.0 : 1.0;
   A.dirE = view == 0 ? -E : E;  // left view looks at x-d in the right image, right view at x+d in the left
   A.vol = L.vol[view];
   A.slab = (size_t)L.W * (size_t)L.H;
@@ -112,6 +114,15 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const double q_disp = m.tab[c][0][dx] + ty[c];  // :155,165
+        if constexpr (SRC == kSrcImg) {
+          const ImgSplit g = split_img(q_disp, A.sgn * q_disp, (double)(qx0 + kRowMod * st), A.Dm1, A.has_valid);
+          const int fxc = min(max(g.fx, -A.pad), A.W + A.pad - 2);  // clamps only taps of the "impossible disparity" branch
+          const int of = ((A.oy0 + dy) * A.Wp + A.pad + fxc) * E;
+          const uint4 o0 = ld_elem<SRC>(A.opx, of), o1 = ld_elem<SRC>(A.opx, of + E);
+          const double cell = img_cell(pix_of<SRC>(P), g_of(P), pix_of<SRC>(o0), g_of(o0), pix_of<SRC>(o1), g_of(o1), g.fw);
+          S[c][ps] += wgt * (g.valid ? cell : A.maxc);
+          continue;
+        }
         const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
         double c0, c1;
         if (SRC == kSrcVolume) {

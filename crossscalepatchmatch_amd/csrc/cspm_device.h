@@ -43,7 +43,10 @@ struct __attribute__((aligned(16))) PixC {
 static_assert(sizeof(PixC) == 16, "PixC must be 16 bytes");
 
 // where the PatchMatch kernels get their cell costs from
-enum { kSrcVolume = 0, kSrcGrd = 1, kSrcCen = 2 };
+enum { kSrcVolume = 0, kSrcGrd = 1, kSrcCen = 2,
+       kSrcImg = 3 };  // GrdPC / CSPC (plane_cost/grd_pc.cc, cspc.cc): no cells at all -- the other view's colour and gradient are
+                       // interpolated at the real-valued column x -+ q_disp.  Elements are PixG with g = Sobel of the 8U gray image;
+                       // the pad cells hold the WRAPPED image columns (HandleBorder, commfunc.h:129-145), so no border branch either
 
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]

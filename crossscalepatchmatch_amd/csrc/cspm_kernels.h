@@ -386,6 +386,28 @@ __global__ void k_gray8(Src s, int W, int H, uint8_t *__restrict__ gray) {
   }
   gray[i] = (uint8_t)((c[0] * 4899 + c[1] * 9617 + c[2] * 1868 + (1 << 13)) >> 14);
 }
+// cvtColor(8UC3, CV_BGR2GRAY) of OpenCV 2.4 (grd_pc.cc:37, cspc.cc:55): the same fixed-point contract, straight from the bytes
+__global__ void k_gray8_u8(const uint32_t *__restrict__ pix, int W, int H, int Wp, int pad, uint8_t *__restrict__ gray) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)W * H) return;
+  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+  const uint32_t q = pix[(size_t)y * Wp + pad + x];
+  gray[i] = (uint8_t)(((int)(q & 255u) * 1868 + (int)((q >> 8) & 255u) * 9617 + (int)((q >> 16) & 255u) * 4899 + (1 << 13)) >> 14);
+}
+// GrdPC / CSPC elements (kSrcImg): g = Sobel(gray8, CV_64F, 1, 0, 1) = gray[x+1] - gray[x-1], REFLECT_101 (grd_pc.cc:40, cspc.cc:58);
+// the pad cells repeat the image periodically, which is what HandleBorder (commfunc.h:129-145) makes of a column outside the image
+__global__ void k_make_aos_img(const uint32_t *__restrict__ pix, const uint8_t *__restrict__ gray, int W, int H, int Wp, int pad,
+                               PixG *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Wp * H) return;
+  const int y = (int)(i / Wp);
+  int x = ((int)(i - (long long)y * Wp) - pad) % W;
+  if (x < 0) x += W;
+  PixG e;
+  e.pix = pix[(size_t)y * Wp + pad + x];
+  e.g = (double)((int)gray[(size_t)y * W + reflect101(x + 1, W)] - (int)gray[(size_t)y * W + reflect101(x - 1, W)]);
+  out[i] = e;
+}
 __device__ __forceinline__ int wrap_mod(int v, int n) {  // (v + n) % n of cen_cc.cc:30,34, kept non-negative for n < 4
   const int r = v % n;
   return r < 0 ? r + n : r;

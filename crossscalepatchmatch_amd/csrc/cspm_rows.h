@@ -52,9 +52,10 @@ __device__ __forceinline__ typename StripReg<SRC>::type ld_strip(const char *row
 // disparity (k-1 for the left view, k+1 for the right view)}: one ds_read_b128 gives a tap its first cell and the colour of
 // its second, one ds_read_b64 of the neighbouring slot the second gradient -- 24 bytes in two LDS instructions at the
 // full 256 B/clk (12-byte ds_read_b96 would run at 96 B/clk, 8-byte reads of 16-byte slots use half the banks).
+// (GrdPC / CSPC: slot k carries the colour of column k+1 for both views -- a tap reads columns fx and fx+1.)
 template <int SRC, int VIEW>
 __device__ __forceinline__ void rd_cells(const char *strip, int adr, uint4 &o0, uint4 &o1) {
-  constexpr int dirS = VIEW == 0 ? -16 : 16;
+  constexpr int dirS = (VIEW == 0 && SRC != kSrcImg) ? -16 : 16;
   if constexpr (SRC == kSrcCen) {
     o0 = *reinterpret_cast<const uint4 *>(strip + adr);
     o1 = *reinterpret_cast<const uint4 *>(strip + adr + dirS);
@@ -74,7 +75,7 @@ __device__ __forceinline__ StageReg<SRC> ld_stage(const char *row, int byte_off)
     r.v = *reinterpret_cast<const uint4 *>(row + (size_t)(unsigned)byte_off);
   } else {
     const u32x3 e = *reinterpret_cast<const u32x3_a4 *>(row + (size_t)(unsigned)byte_off);
-    const uint32_t nb = *reinterpret_cast<const uint32_t *>(row + (size_t)(unsigned)(byte_off + (VIEW == 0 ? -E : E) + 8));
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(row + (size_t)(unsigned)(byte_off + ((VIEW == 0 && SRC != kSrcImg) ? -E : E) + 8));
     r.v = uint4{e.x, e.y, e.z, nb};
   }
   return r;
@@ -88,7 +89,7 @@ __device__ __forceinline__ uint4 rd_own(const char *ostrip, int adr_g, int adr_p
   } else {
     const uint32_t pix = *reinterpret_cast<const uint32_t *>(ostrip + adr_p + j * 4);
     uint2 g{0u, 0u};
-    if constexpr (SRC == kSrcGrd) g = *reinterpret_cast<const uint2 *>(ostrip + adr_g + j * 8);
+    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) g = *reinterpret_cast<const uint2 *>(ostrip + adr_g + j * 8);
     return uint4{g.x, g.y, pix, 0u};
   }
 }
@@ -97,7 +98,7 @@ __device__ __forceinline__ void wr_own(char *ostrip, int ocap, int idx, const ty
   if constexpr (SRC == kSrcCen) {
     *reinterpret_cast<uint4 *>(ostrip + idx * 16) = e;
   } else {
-    if constexpr (SRC == kSrcGrd) *reinterpret_cast<uint2 *>(ostrip + idx * 8) = uint2{e.x, e.y};
+    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) *reinterpret_cast<uint2 *>(ostrip + idx * 8) = uint2{e.x, e.y};
     *reinterpret_cast<uint32_t *>(ostrip + ocap * 8 + idx * 4) = e.z;
   }
 }
@@ -158,6 +159,9 @@ struct RowSrc {
   // unstaged: image rows in global memory and the byte offset of the lane's window column 0
   const char *own_row, *oth_row;
   int lane_off;
+  // GrdPC / CSPC: the other view is addressed by image column fx (wave-uniform base, no per-lane part), clamped into the
+  // range the strip / the padded row holds (only taps of the "impossible disparity" branch are ever clamped)
+  int img_base, fx_lo, fx_hi;
 };
 
 // CNT consecutive taps (window columns g0 .. g0+CNT-1, CNT <= 7) of one window row for all 64 lanes, accumulated into the
@@ -191,12 +195,26 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
   for (int k = 0; k < N; ++k) {
     const int j = J0 + k;
     const double q_disp = pa * qx_d + rowterm;  // :165
+    in_img[k] = true;
+    if (EDGE) in_img[k] = (unsigned)(e_rel + j) <= (unsigned)e_span;
+    if constexpr (SRC == kSrcImg) {
+      const ImgSplit g = split_img(q_disp, VIEW == 0 ? -q_disp : q_disp, qx_d, A.Dm1, A.has_valid);  // qx_d: still this tap's column
+      qx_d += 1.0;
+      fr[k] = g.fw;
+      valid[k] = g.valid;
+      const int fxc = min(max(g.fx, R.fx_lo), R.fx_hi);
+      if (STAGED) {
+        rd_cells<SRC, VIEW>(R.strip, fxc * 16 + R.img_base, o0[k], o1[k]);
+      } else {
+        o0[k] = ld_elem<SRC>(R.oth_row, fxc * E + R.img_base);
+        o1[k] = ld_elem<SRC>(R.oth_row, fxc * E + R.img_base + E);
+      }
+      continue;
+    }
     qx_d += 1.0;                                // exact: small integers
     const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
     fr[k] = d.fr;
     valid[k] = d.valid;
-    in_img[k] = true;
-    if (EDGE) in_img[k] = (unsigned)(e_rel + j) <= (unsigned)e_span;
     if (SRC == kSrcVolume) {
       const int qx = in_img[k] ? cx_lane - A.half + g0 + j : cx_lane;
       const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
@@ -217,7 +235,11 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
     wgt[k] = lut.w[sad];
   }
   // stage 4: cell costs (the colour term is the third round trip), interpolated (:171-175)
-  if (SRC != kSrcVolume) {
+  if constexpr (SRC == kSrcImg) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      tmp[k] = img_cell(pix_of<SRC>(P[k]), g_of(P[k]), pix_of<SRC>(o0[k]), g_of(o0[k]), pix_of<SRC>(o1[k]), g_of(o1[k]), fr[k]);
+  } else if (SRC != kSrcVolume) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const double c0 = cell_of<SRC>(lut.a, P[k], o0[k]);
@@ -341,6 +363,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   R.adr_g = (cx - cmin) * (SRC == kSrcCen ? 16 : 8);
   R.adr_p = ctx.ocap * 8 + (cx - cmin) * 4;
   R.lane_off = (L.pad + cx - A.half) * E;
+  R.img_base = staged ? (L.pad - s_lo) * 16 : L.pad * E;
+  R.fx_lo = staged ? s_lo - L.pad : -L.pad;
+  R.fx_hi = staged ? s_hi - 1 - L.pad : L.W + L.pad - 2;
   const uint32_t Ip = SRC == kSrcCen ? L.pc[VIEW][cy * L.Wp + L.pad + cx].pix : L.px[VIEW][cy * L.Wp + L.pad + cx].pix;
   const double qx0_d = (double)(cx - A.half);
   const int e_lo = max(0, A.half - cx);                           // first window column inside the image

@@ -120,6 +120,41 @@ __device__ __forceinline__ double tap_value(const DispSplit &s, double c0, doubl
   return wgt * tmp;            // :176
 }
 
+// ---- GrdPC / CSPC tap (plane_cost/grd_pc.cc:125-169 without USE_INTER, cspc.cc:145-174) ----
+//   valid  <=> static_cast<int>(q_disp) in [1, D-1], as above
+//   fx     = static_cast<int>(other_x), other_x = q_x + (2*view-1)*q_disp (`signed_disp` = that product: exact, +-q_disp)
+//   fw     = floor_wgt = (fx+1) - other_x   (truncation, not floor: other_x < 0 near the left border gives weights > 1,
+//            exactly as the reference computes them)
+struct ImgSplit {
+  bool valid;
+  int fx;
+  double fw;
+};
+__device__ __forceinline__ ImgSplit split_img(double q_disp, double signed_disp, double qx_d, int Dm1, bool level_has_valid) {
+  ImgSplit s;
+  const int f0 = cvt_i32_sat(q_disp);
+  s.valid = (med3_i32(f0, 1, Dm1) == f0) & level_has_valid;
+  const double other_x = qx_d + signed_disp;
+  s.fx = cvt_i32_sat(other_x);
+  s.fw = (double)(int)((unsigned)s.fx + 1u) - other_x;
+  return s;
+}
+// colour (B, G, R in the reference's channel order) and gradient of the other view interpolated between columns fx and fx+1,
+// truncated absolute differences: COST_ALPHA*min(clr,TAU_CLR) + (1-COST_ALPHA)*min(grd,TAU_GRD)
+__device__ __forceinline__ double img_cell(uint32_t Iq, double Gq, uint32_t If, double Gf, uint32_t Ic, double Gc, double fw) {
+  double t[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int q = (int)((Iq >> (8 * k)) & 255u), c = (int)((Ic >> (8 * k)) & 255u), f = (int)((If >> (8 * k)) & 255u);
+    t[k] = fabs((double)(q - c) + fw * (double)(c - f));  // I_q - I_ceil + floor_wgt * (I_ceil - I_floor)
+  }
+  double clr = t[0] + t[1];
+  clr = clr + t[2];
+  clr *= 0.33333333333333;
+  const double grd = fabs((Gq - Gc) + fw * (Gc - Gf));
+  return 0.1 * __builtin_fmin(clr, 10.0) + (1 - 0.1) * __builtin_fmin(grd, 2.0);
+}
+
 // balanced binary tree over the 64 lanes (neighbours first): every lane ends with the same bits because a+b == b+a
 __device__ __forceinline__ double wave_tree_sum(double v) {
 #pragma unroll

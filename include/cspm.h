@@ -88,6 +88,13 @@ int cspm_set_option(cspm_ctx *ctx, int key, long long value);
  * the device; Hamming cells are computed on the fly from the codes (default) or materialised as f64 volumes
  * (CSPM_OPT_GRD_VOLUMES = 1), exactly like the GRD cost. */
 int cspm_build_cost_cen(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
+/* The two volume-free IPlaneCost implementations the reference also ships (not instantiated by its main.cc):
+ *   scale_num == 0 -> `new GrdPC(l_img, r_img, max_disp, wnd_size)`                          plane_cost/grd_pc.h:27-29, grd_pc.cc:11-66
+ *   scale_num >= 1 -> `new CSPC(l_img, r_img, max_disp, wnd_size, scale_num, reg_lambda)`    plane_cost/cspc.h:21-23,  cspc.cc:11-93
+ * GetPlaneCost (grd_pc.cc:72-176, cspc.cc:107-183) interpolates the other view's colour and 8U-gray x-gradient at the
+ * real-valued column x -+ q_disp (wrap-around HandleBorder) instead of interpolating pre-computed cells; the "impossible
+ * disparity" cost is the constant COST_ALPHA*TAU_CLR + (1-COST_ALPHA)*TAU_GRD.  cspm_get_cost_slab is an error for these. */
+int cspm_build_cost_img(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);
 /* Foreign CCMethod plugins (cc_method.h:31-32): allocate like the constructors above, then upload
  * the host volumes the plugin filled slab by slab, then finalize (max_cost reduction). */
 int cspm_begin_cost(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num, double reg_lambda);

@@ -377,6 +377,8 @@ struct csor_pc {
   int wid[CSOR_MAX_LEVELS], hei[CSOR_MAX_LEVELS], max_disp[CSOR_MAX_LEVELS];
   uint8_t *img[2][CSOR_MAX_LEVELS];
   double *vol[2][CSOR_MAX_LEVELS];
+  int img_kind;  /* 1: GrdPC / CSPC -- no volumes, cells computed from the images at real-valued positions */
+  double *grd[2][CSOR_MAX_LEVELS]; /* GrdPC::grd_x_ / CSPC::grd_x_ (img_kind only) */
   double max_cost[2][CSOR_MAX_LEVELS];
   double scale_wgt[CSOR_MAX_LEVELS];
   double lookup_exp[1000];
@@ -393,7 +395,35 @@ static double *bgr8_to_rgb64(const uint8_t *bgr, int w, int h) {
   return o;
 }
 
+
+/* ---- GrdPC / CSPC ingredients (plane_cost/grd_pc.h:13-17, cspc.h:13-17) ---- */
+#define IMG_COST_ALPHA 0.1
+#define IMG_TAU_CLR 10.0
+#define IMG_TAU_GRD 2.0
+/* cvtColor(8UC3, CV_BGR2GRAY), OpenCV 2.4: (B*1868 + G*9617 + R*4899 + (1<<13)) >> 14   (grd_pc.cc:37, cspc.cc:55) */
+static void bgr8_to_gray8(const uint8_t *bgr, int w, int h, uint8_t *gray) {
+  for (size_t i = 0; i < (size_t)w * h; ++i)
+    gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+}
+/* Sobel(gray8U, CV_64F, 1, 0, ksize=1): [-1 0 1], BORDER_REFLECT_101   (grd_pc.cc:40, cspc.cc:58) */
+static void sobel_x_ks1_u8(const uint8_t *gray, int w, int h, double *grd) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int xm = x - 1, xp = x + 1;
+      if (w == 1) { xm = 0; xp = 0; }
+      else { if (xm < 0) xm = -xm; if (xp >= w) xp = 2 * (w - 1) - xp; }
+      grd[(size_t)y * w + x] = (double)((int)gray[(size_t)y * w + xp] - (int)gray[(size_t)y * w + xm]);
+    }
+}
+/* commfunc.h:129-145 */
+static inline int handle_border(int loc, int size) {
+  if (loc < 0) return loc + size;
+  if (loc >= size) return loc - size;
+  return loc;
+}
+
 void csor_pc_refresh_max_cost(csor_pc *pc) { /* pre_cs_pc.cc:75-82, pre_ss_pc.cc:51-58 */
+  if (pc->img_kind) return;
   for (int v = 0; v < 2; ++v)
     for (int s = 0; s < pc->scale_num; ++s) {
       double m = -1.0;
@@ -433,6 +463,25 @@ csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, in
         csor_pyrdown_bgr8(pc->img[v][s - 1], pc->wid[s - 1], pc->hei[s - 1], pc->img[v][s]);
       }
     }
+  if (cc_kind == CSOR_CC_IMG) {
+    /* GrdPC (grd_pc.cc:27-49) / CSPC (cspc.cc:37-61): per level cvtColor(BGR2GRAY) on 8UC3 and Sobel(gray, CV_64F, 1, 0, 1).
+     * No volumes; the "impossible disparity" cost is the constant of grd_pc.cc:131-132 / cspc.cc:150-152. */
+    pc->img_kind = 1;
+    for (int v = 0; v < 2; ++v)
+      for (int s = 0; s < pc->scale_num; ++s) {
+        const int W = pc->wid[s], H = pc->hei[s];
+        uint8_t *gray = (uint8_t *)malloc((size_t)W * H);
+        bgr8_to_gray8(pc->img[v][s], W, H, gray);
+        pc->grd[v][s] = (double *)malloc(sizeof(double) * (size_t)W * H);
+        sobel_x_ks1_u8(gray, W, H, pc->grd[v][s]);
+        free(gray);
+        pc->max_cost[v][s] = IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD;
+      }
+    if (pc->cs) csor_scale_weights(pc->scale_num, reg_lambda, pc->scale_wgt); /* cspc.cc:63-87 */
+    else pc->scale_wgt[0] = 1.0;
+    csor_exp_lut(pc->lookup_exp, WGT_GAMMA); /* grd_pc.cc:61-64, cspc.cc:88-92 */
+    return pc;
+  }
   /* pre_cs_pc.cc:57-84: volumes with max_disp_s+1 slabs, built with maxDis = max_disp_s+1 */
   for (int s = 0; s < pc->scale_num; ++s) {
     double *tl = bgr8_to_rgb64(pc->img[0][s], pc->wid[s], pc->hei[s]);
@@ -460,7 +509,7 @@ csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, in
 void csor_pc_destroy(csor_pc *pc) {
   if (!pc) return;
   for (int v = 0; v < 2; ++v)
-    for (int s = 0; s < pc->scale_num; ++s) { free(pc->img[v][s]); free(pc->vol[v][s]); }
+    for (int s = 0; s < pc->scale_num; ++s) { free(pc->img[v][s]); free(pc->vol[v][s]); free(pc->grd[v][s]); }
   free(pc);
 }
 int csor_pc_levels(const csor_pc *pc) { return pc->scale_num; }
@@ -485,6 +534,30 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
   const double wgt = pc->lookup_exp[sum];
   double q_disp = plane_a * q_x + q_disp_y;
   int q_disp_floor = trunc_x86(q_disp);
+  if (pc->img_kind) {
+    /* GrdPC::GetPlaneCost (grd_pc.cc:128-169, the !USE_INTER build) / CSPC::GetPlaneCost (cspc.cc:147-174) */
+    if (q_disp_floor <= 0 || q_disp_floor >= pc->max_disp[s])
+      return wgt * (IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD);
+    const int W = pc->wid[s];
+    const double other_x = q_x + (2 * view - 1) * q_disp;
+    int floor_x = trunc_x86(other_x);
+    int ceil_x = floor_x + 1;
+    const double floor_wgt = ceil_x - other_x;
+    floor_x = handle_border(floor_x, W);
+    ceil_x = handle_border(ceil_x, W);
+    const uint8_t *I_other_y = pc->img[1 - view][s] + (size_t)q_y * W * 3;
+    const uint8_t *I_floor = I_other_y + 3 * floor_x, *I_ceil = I_other_y + 3 * ceil_x;
+    double clr_cost = fabs(I_q[0] - I_ceil[0] + floor_wgt * (I_ceil[0] - I_floor[0])) +
+                      fabs(I_q[1] - I_ceil[1] + floor_wgt * (I_ceil[1] - I_floor[1])) +
+                      fabs(I_q[2] - I_ceil[2] + floor_wgt * (I_ceil[2] - I_floor[2]));
+    clr_cost *= 0.33333333333333;
+    const double *G_other_y = pc->grd[1 - view][s] + (size_t)q_y * W;
+    const double G_floor = G_other_y[floor_x], G_ceil = G_other_y[ceil_x];
+    const double G_q = pc->grd[view][s][(size_t)q_y * W + q_x];
+    const double grd_cost = fabs(G_q - G_ceil + floor_wgt * (G_ceil - G_floor));
+    return wgt * (IMG_COST_ALPHA * (clr_cost < IMG_TAU_CLR ? clr_cost : IMG_TAU_CLR) +
+                  (1 - IMG_COST_ALPHA) * (grd_cost < IMG_TAU_GRD ? grd_cost : IMG_TAU_GRD));
+  }
   if (q_disp_floor <= 0 || q_disp_floor >= pc->max_disp[s]) return wgt * pc->max_cost[view][s];
   int q_disp_ceil = q_disp_floor + 1;
   const double floor_wgt = q_disp_ceil - q_disp;

@@ -73,7 +73,8 @@ void   csor_sobel_x_ks1(const float *gray, int w, int h, double *grd);
  * RGB2GRAY fixed-point contract), Hamming distance, 80 where the other view is outside the image */
 void   csor_cen_build_cv(const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, double *vol);
 void   csor_cen_build_right_cv(const double *l_rgb, const double *r_rgb, int w, int h, int maxDis, double *vol);
-enum { CSOR_CC_GRD = 0, CSOR_CC_CEN = 1 };  /* main.cc:39-55 GetCCType("GRD" / "CEN") */
+enum { CSOR_CC_GRD = 0, CSOR_CC_CEN = 1,  /* main.cc:39-55 GetCCType("GRD" / "CEN") */
+       CSOR_CC_IMG = 2 };                   /* no CCMethod at all: GrdPC / CSPC (plane_cost/grd_pc.cc, cspc.cc) */
 
 /* ---------------- plane cost objects: PreSSPC / PreCSPC ---------------- */
 typedef struct csor_pc csor_pc;
@@ -82,6 +83,9 @@ typedef struct csor_pc csor_pc;
  * l_bgr/r_bgr: packed 8UC3 BGR, h rows of w*3 bytes.  cost function: GRD. */
 csor_pc *csor_pc_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h,
                         int max_disp, int wnd_size, int scale_num, double reg_lambda);
+/* cc_kind == CSOR_CC_IMG: scale_num == 0 -> GrdPC (plane_cost/grd_pc.cc:11-66, 72-176), scale_num >= 1 -> CSPC
+ * (plane_cost/cspc.cc:11-93, 107-183): the volume-free IPlaneCost variants that interpolate the other view's colour and
+ * gradient at the real-valued position x -+ q_disp instead of interpolating pre-computed cells.  csor_pc_volume() is NULL. */
 csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h,
                            int max_disp, int wnd_size, int scale_num, double reg_lambda, int cc_kind);
 void     csor_pc_destroy(csor_pc *pc);

@@ -109,14 +109,14 @@ def _bgr(img):
 
 
 class PlaneCost:
-    """PreSSPC (scale_num=0) / PreCSPC (scale_num>=1) with the GRD cost."""
+    """PreSSPC (scale_num=0) / PreCSPC (scale_num>=1) with the GRD or CEN cost; cc="IMG": GrdPC (scale_num=0) / CSPC."""
 
     def __init__(self, l_bgr, r_bgr, max_disp, wnd_size=35, scale_num=0, reg_lambda=0.0, cc="GRD"):
         self.L = lib()
         self.l, self.r = _bgr(l_bgr), _bgr(r_bgr)
         self.h, self.w = self.l.shape[:2]
         self.p = self.L.csor_pc_create_cc(_u8(self.l), _u8(self.r), self.w, self.h, max_disp, wnd_size, scale_num,
-                                          reg_lambda, {"GRD": 0, "CEN": 1}[cc])
+                                          reg_lambda, {"GRD": 0, "CEN": 1, "IMG": 2}[cc])
         if not self.p:
             raise ValueError("csor_pc_create failed")
         self.levels = self.L.csor_pc_levels(self.p)

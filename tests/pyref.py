@@ -110,6 +110,16 @@ def cen_volume(l_bgr, r_bgr, max_dis_slabs, right):  # cen_cc.cc:4-137
     return vol
 
 
+def img_grad(bgr):  # grd_pc.cc:37-40 / cspc.cc:55-58: cvtColor(8UC3, BGR2GRAY) fixed point, Sobel(.., CV_64F, 1, 0, 1)
+    b, g, r = (bgr[..., k].astype(np.int64) for k in range(3))
+    gray = (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14
+    h, w = gray.shape
+    out = np.zeros((h, w))
+    for x in range(w):
+        out[:, x] = gray[:, reflect101(x + 1, w)] - gray[:, reflect101(x - 1, w)]
+    return out
+
+
 def plane_param(n, p):  # plane.h:25-34
     den = max(abs(n[2]), EPS)
     if n[2] < 0.0:
@@ -135,8 +145,15 @@ class PlaneCost:
                 self.img[v].append(pyrdown(self.img[v][s - 1]))
             w, h, d = self.dims[-1]
             self.dims.append(((w + 1) // 2, (h + 1) // 2, d // 2))
-        self.vol = [[build(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1) for s in range(S)] for v in (0, 1)]
-        self.max_cost = [[max(-1.0, float(self.vol[v][s].max())) for s in range(S)] for v in (0, 1)]
+        self.img_kind = cc == "IMG"
+        if self.img_kind:
+            # GrdPC (grd_pc.cc:27-49) / CSPC (cspc.cc:37-61): 8U gray, Sobel [-1 0 1] -> CV_64F; no volumes
+            self.grd = [[img_grad(self.img[v][s]) for s in range(S)] for v in (0, 1)]
+            self.vol = [[None] * S, [None] * S]
+            self.max_cost = [[0.1 * 10.0 + (1 - 0.1) * 2.0] * S for v in (0, 1)]  # grd_pc.cc:131-132, cspc.cc:150-152
+        else:
+            self.vol = [[build(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1) for s in range(S)] for v in (0, 1)]
+            self.max_cost = [[max(-1.0, float(self.vol[v][s].max())) for s in range(S)] for v in (0, 1)]
         if self.cs:
             M = np.zeros((S, S))
             for s in range(S):
@@ -179,6 +196,8 @@ class PlaneCost:
                 f = int(qd) if (qd == qd and abs(qd) < 2 ** 31) else -(2 ** 31)  # cvttsd2si
                 if f <= 0 or f >= D:
                     term = wgt * maxc
+                elif self.img_kind:
+                    term = wgt * self._img_cell(v, s, qx, qy, qd)
                 else:
                     fw = (f + 1) - qd
                     term = wgt * (fw * vol[f, qy, qx] + (1 - fw) * vol[f + 1, qy, qx])
@@ -196,6 +215,27 @@ class PlaneCost:
                 rows = [rows[i] + rows[i + 1] for i in range(0, len(rows), 2)]
             cost = rows[0]
         return cost
+
+    def _img_cell(self, v, s, qx, qy, qd):
+        """grd_pc.cc:151-168 / cspc.cc:154-173: colour and gradient of the other view interpolated at qx -+ q_disp"""
+        w = self.dims[s][0]
+        ox = qx + (2 * v - 1) * qd
+        fx = int(ox)  # static_cast<int>: towards zero
+        cxx = fx + 1
+        fw = cxx - ox
+        wrap = lambda t: t + w if t < 0 else (t - w if t >= w else t)  # commfunc.h:129-145
+        fx, cxx = wrap(fx), wrap(cxx)
+        Iq = self.img[v][s][qy, qx].astype(np.int64)
+        If = self.img[1 - v][s][qy, fx].astype(np.int64)
+        Ic = self.img[1 - v][s][qy, cxx].astype(np.int64)
+        clr = 0.0
+        for ch in range(3):
+            t = abs(float(int(Iq[ch] - Ic[ch])) + fw * float(int(Ic[ch] - If[ch])))
+            clr = t if ch == 0 else clr + t
+        clr *= 0.33333333333333
+        G = self.grd
+        grd = abs(G[v][s][qy, qx] - G[1 - v][s][qy, cxx] + fw * (G[1 - v][s][qy, cxx] - G[1 - v][s][qy, fx]))
+        return 0.1 * min(clr, 10.0) + (1 - 0.1) * min(grd, 2.0)
 
     def cost(self, x, y, norm, param, v, rowmod=0):
         if not self.cs:

@@ -175,3 +175,59 @@ def test_census_gray_contract():
     assert list(g) == [255, 76, 150, 29, 22]  # e.g. (30*4899 + 20*9617 + 10*1868 + 8192) >> 14 = 22
     # identical views: zero cost wherever the other view is inside the image, 80 outside
     assert np.all(pc.volume(0, 0)[0] == 0) and np.all(pc.volume(0, 0)[1][:, 0] == 80)
+
+
+@pytest.mark.parametrize("wnd", [5, 9])
+@pytest.mark.parametrize("scale_num,lam", [(0, 0.0), (3, 0.3), (5, 1.0)])
+def test_grdpc_cspc_plane_cost(scale_num, lam, wnd):
+    """GrdPC (plane_cost/grd_pc.cc:72-176) / CSPC (cspc.cc:107-183): the volume-free variants -- the other view's colour and
+    gradient interpolated at x -+ q_disp, wrap-around HandleBorder, constant "impossible disparity" cost."""
+    l, r = _tiny(30, 22, 10, 12)
+    pc = po.PlaneCost(l, r, 10, wnd, scale_num, lam, cc="IMG")
+    ref = pyref.PlaneCost(l, r, 10, wnd, scale_num, lam, cc="IMG")
+    assert pc.max_cost(0, 0) == ref.max_cost[0][0] == 0.1 * 10.0 + (1 - 0.1) * 2.0
+    rng = np.random.default_rng(18)
+    seen_valid = 0
+    for i in range(80):
+        x, y, v = int(rng.integers(0, 30)), int(rng.integers(0, 22)), int(rng.integers(0, 2))
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if i < 20: n = np.array([0.0, 0.0, 1.0])  # fronto-parallel: every tap in range
+        if i in (20, 21): x = 0 if v == 0 else 29  # other_x leaves the image: the wrap-around of HandleBorder
+        z = rng.uniform(0.5, 9.5)
+        prm = po.plane_param(n, [x, y, z])
+        got = pc.cost(x, y, n, prm, v, po.SUM_SERIAL)
+        assert got == ref.cost(x, y, n, prm, v), (i, x, y, v)
+        dev = pc.cost(x, y, n, prm, v, po.SUM_DEVICE)
+        assert dev == ref.cost(x, y, n, prm, v, rowmod=7), (i, x, y, v)
+        assert abs(dev - got) <= 1e-12 * max(1.0, abs(got))
+        seen_valid += got < 0.999 * pc.max_cost(0, 0) * pc.taps(x, y) * (1.0 if scale_num == 0 else 2.0)
+    assert seen_valid > 20
+
+
+def test_grdpc_matches_the_pixel_cost_of_a_true_shift():
+    """A right image that is the left shifted by exactly 3 px: a fronto-parallel plane at d = 3.5 interpolates halfway between
+    two columns (floor_wgt = 0.5) -- cost > 0; at d = 3 + 1e-9 the tap sits on the true match and every cell is ~0."""
+    rng = np.random.default_rng(5)
+    l = rng.integers(0, 256, (16, 40, 3), dtype=np.uint8)
+    r = np.roll(l, -3, axis=1)
+    pc = po.PlaneCost(l, r, 8, 5, 0, 0.0, cc="IMG")
+    n = np.array([0.0, 0.0, 1.0])
+    near = pc.cost(20, 8, n, po.plane_param(n, [20, 8, 3.000000001]), 0, po.SUM_SERIAL)
+    half = pc.cost(20, 8, n, po.plane_param(n, [20, 8, 3.5]), 0, po.SUM_SERIAL)
+    assert near < 1e-6 < half
+
+
+def test_grdpc_whole_patchmatch_against_second_restatement():
+    l, r = _tiny(14, 9, 6, 14)
+    for scale_num, lam in ((0, 0.0), (2, 0.3)):
+        pc = po.PlaneCost(l, r, 6, 5, scale_num, lam, cc="IMG")
+        rpc = pyref.PlaneCost(l, r, 6, 5, scale_num, lam, cc="IMG")
+        pm = po.PatchMatch(l, r, 6, 16)
+        ref = pyref.PatchMatch(l, r, 6, 16, seed=31)
+        kw = dict(seed=31, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+        pm.init(pc, **kw); ref.init(rpc)
+        for phase in ("spatial", "view", "refine"):
+            getattr(pm, phase)(0, pc, **kw); getattr(ref, phase)(0, rpc)
+            for v in (0, 1):
+                np.testing.assert_array_equal(pm.planes(v)[..., 6:9], ref.prm[v], err_msg=phase)
+                np.testing.assert_array_equal(pm.min_cost(v), ref.cost[v], err_msg=phase)
