@@ -64,12 +64,9 @@ void DevicePlaneCost::release_kept_context() {
   kept_device_ = -1;
 }
 
-DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num,
-                                 CCMethod *cc_method, double reg_lambda)
-    : ctx_(NULL), ctx_device_(device) {
-  CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // pre_cs_pc.cc:25, pre_ss_pc.cc:24
+void DevicePlaneCost::open_context(const Mat &l_img, const Mat &r_img) {
+  CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // pre_cs_pc.cc:25, pre_ss_pc.cc:24, grd_pc.cc:22, cspc.cc:24
   CV_Assert(l_img.rows == r_img.rows && l_img.cols == r_img.cols);
-  if (!cc_method) throw std::runtime_error("PreSSPC/PreCSPC: NULL CCMethod (unknown --cc_name)");  // the reference dereferences it
   if (kept_ctx_ && kept_device_ == device) {
     ctx_ = kept_ctx_;
     kept_ctx_ = NULL;
@@ -78,6 +75,20 @@ DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_dis
   }
   const Mat l = l_img.clone(), r = r_img.clone();  // packed rows
   check(cspm_set_images(ctx_, l.data, r.data, l.cols, l.rows, l.step), ctx_, "cspm_set_images");
+}
+
+// GrdPC / CSPC
+DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, double reg_lambda)
+    : ctx_(NULL), ctx_device_(device) {
+  open_context(l_img, r_img);
+  check(cspm_build_cost_img(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_img");
+}
+
+DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num,
+                                 CCMethod *cc_method, double reg_lambda)
+    : ctx_(NULL), ctx_device_(device) {
+  if (!cc_method) throw std::runtime_error("PreSSPC/PreCSPC: NULL CCMethod (unknown --cc_name)");  // the reference dereferences it
+  open_context(l_img, r_img);
   if (dynamic_cast<GrdCC *>(cc_method)) {
     // the known cost function: pyramid, gradients, max_cost, scale weights all on the device
     check(cspm_build_cost_grd(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_grd");

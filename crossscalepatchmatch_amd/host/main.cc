@@ -4,6 +4,8 @@
 #include "commfunc.h"
 #include "cs_patchmatch.h"
 #include "get_method.h"
+#include "plane_cost/cspc.h"
+#include "plane_cost/grd_pc.h"
 #include "plane_cost/pre_cs_pc.h"
 #include "plane_cost/pre_ss_pc.h"
 #include "pfm_io.h"
@@ -20,6 +22,8 @@ DEFINE_string(r_dis_file, "r_dis.png", "right disparity map to write (8-bit)");
 DEFINE_int32(max_dis, 0, "disparity search range");
 DEFINE_int32(dis_scale, 0, "factor applied to disparities before 8-bit quantisation");
 DEFINE_string(cc_name, "CCName", "matching cost: GRD | CEN");
+DEFINE_string(pc_name, "PRE", "plane cost family: PRE = PreSSPC / PreCSPC over --cc_name's cost volumes (the reference's main.cc); "
+                              "IMG = GrdPC / CSPC, the volume-free colour + gradient costs (main.cc:106-107, commented out there)");
 DEFINE_bool(use_cs, false, "cross-scale aggregation over a 5-level pyramid (PreCSPC) instead of PreSSPC");
 DEFINE_bool(use_pp, false, "left-right check, hole filling and weighted median afterwards");
 DEFINE_double(reg_lambda, 0.0, "cross-scale regularisation weight");
@@ -50,9 +54,13 @@ int run_pair(const PairFiles &f, CCMethod *cost_fn) {
     return EXIT_FAILURE;
   }
   const double t0 = static_cast<double>(getTickCount());
-  IPlaneCost *plane_cost =
-      FLAGS_use_cs ? static_cast<IPlaneCost *>(new PreCSPC(left, right, FLAGS_max_dis, kWindow, kScales, cost_fn, FLAGS_reg_lambda))
-                   : static_cast<IPlaneCost *>(new PreSSPC(left, right, FLAGS_max_dis, kWindow, cost_fn));
+  IPlaneCost *plane_cost;
+  if (FLAGS_pc_name == "IMG")
+    plane_cost = FLAGS_use_cs ? static_cast<IPlaneCost *>(new CSPC(left, right, FLAGS_max_dis, kWindow, kScales, FLAGS_reg_lambda))
+                              : static_cast<IPlaneCost *>(new GrdPC(left, right, FLAGS_max_dis, kWindow));
+  else
+    plane_cost = FLAGS_use_cs ? static_cast<IPlaneCost *>(new PreCSPC(left, right, FLAGS_max_dis, kWindow, kScales, cost_fn, FLAGS_reg_lambda))
+                              : static_cast<IPlaneCost *>(new PreSSPC(left, right, FLAGS_max_dis, kWindow, cost_fn));
   CSPatchMatch matcher(left, right, FLAGS_max_dis, FLAGS_dis_scale);
   matcher.set_seed(static_cast<uint64_t>(FLAGS_seed));
   matcher.set_schedule(FLAGS_schedule == "redblack" ? 1 : 0);

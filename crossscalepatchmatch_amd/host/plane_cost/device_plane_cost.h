@@ -1,4 +1,4 @@
-// device_plane_cost.h -- common implementation of PreSSPC / PreCSPC above the C ABI (include/cspm.h).
+// device_plane_cost.h -- common implementation of PreSSPC / PreCSPC / GrdPC / CSPC above the C ABI (include/cspm.h).
 #pragma once
 #include "../cc_method.h"
 #include "i_plane_cost.h"
@@ -8,6 +8,8 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
   // scale_num == 0: PreSSPC (pre_ss_pc.cc:12-65); >= 1: PreCSPC (pre_cs_pc.cc:12-115).  cc_method is borrowed.
   DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, CCMethod *cc_method,
                   double reg_lambda);
+  // the volume-free variants, no CCMethod: scale_num == 0: GrdPC (grd_pc.cc:11-66); >= 1: CSPC (cspc.cc:11-93)
+  DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, double reg_lambda);
   ~DevicePlaneCost();
   virtual double GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const;
   virtual cspm_ctx *device_ctx() const { return ctx_; }
@@ -20,6 +22,7 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
  private:
   DevicePlaneCost(const DevicePlaneCost &);
   void upload_foreign(CCMethod *cc, int view, int level);
+  void open_context(const Mat &l_img, const Mat &r_img);
   cspm_ctx *ctx_;
   int ctx_device_;
   static cspm_ctx *kept_ctx_;

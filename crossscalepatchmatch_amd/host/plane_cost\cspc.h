@@ -1,4 +1,4 @@
-// CSPM/main.cc:13-14 includes "plane_cost\cspc.h" but never instantiates CSPC (main.cc:106-107 are commented out).
-// Forwarding stub so that the reference's main.cc compiles unchanged; see the real header for what is offered.
+// CSPM/main.cc:13-14 includes "plane_cost\\cspc.h" (Windows path separator).  Forwarding header so that the reference's
+// main.cc compiles unchanged; the class CSPC lives in the real header.
 #pragma once
 #include "plane_cost/cspc.h"

@@ -194,3 +194,44 @@ def test_foreign_ccmethod_plugin_through_the_cpp_layer(gpu_ctx, small_pair, tmp_
     pm.run(2, pc, False, seed=99, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
     np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "ol.pgm")), pm.dis(0))
     np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "or.pgm")), pm.dis(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_cs", [0, 1])
+def test_grdpc_cspc_classes_through_the_cpp_layer(gpu_ctx, small_pair, tmp_path, use_cs):
+    """`new GrdPC(...)` / `new CSPC(...)` (plane_cost/grd_pc.h:27-29, cspc.h:21-23) with the reference's constructor signatures:
+    per-call GetPlaneCost and the whole PatchMatch + post-processing == oracle; the CLI reaches them with --pc_name=IMG."""
+    from oracle import pyoracle as po
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "img_pc_check")
+    pkg = os.path.join(ROOT, "crossscalepatchmatch_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", HOST, "-o", exe, os.path.join(ROOT, "tests", "helpers", "img_pc_check.cc"),
+                           os.path.join(HOST, "host_impl.cc"), os.path.join(HOST, "image_io.cc"), "-L", pkg, "-lcspm_hip", "-lz",
+                           "-Wl,-rpath," + pkg])
+    l, r, D = small_pair["l"], small_pair["r"], small_pair["max_dis"]
+    pngio.write_pnm(str(tmp_path / "l.ppm"), l[..., ::-1])
+    pngio.write_pnm(str(tmp_path / "r.ppm"), r[..., ::-1])
+    txt = subprocess.check_output([exe, str(tmp_path / "l.ppm"), str(tmp_path / "r.ppm"), str(D), str(use_cs), str(tmp_path / "ol.pgm"),
+                                   str(tmp_path / "or.pgm")]).decode().split()
+    pc = po.PlaneCost(l, r, D, 35, 3 if use_cs else 0, 0.3 if use_cs else 0.0, cc="IMG")
+    pts = [(0, 0, 0), (small_pair["w"] // 2, small_pair["h"] // 2, 1), (small_pair["w"] - 1, small_pair["h"] - 1, 0)]
+    for (x, y, v), got in zip(pts, txt):
+        n = np.array([0.1, -0.2, 0.97])
+        assert float(got) == pc.cost(x, y, n, po.plane_param(n, [x, y, 4.25]), v, po.SUM_DEVICE)
+    pm = po.PatchMatch(l, r, D, 4)
+    pm.run(2, pc, True, seed=99, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "ol.pgm")), pm.dis(0))
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "or.pgm")), pm.dis(1))
+    # the command line: --pc_name=IMG
+    cli = os.path.join(pkg, "cspm_main")
+    subprocess.check_call([cli, f"--l_img_file={tmp_path}/l.ppm", f"--r_img_file={tmp_path}/r.ppm", f"--l_dis_file={tmp_path}/cl.pgm",
+                           f"--r_dis_file={tmp_path}/cr.pgm", f"--max_dis={D}", "--dis_scale=4", "--pc_name=IMG", "--cc_name=GRD",
+                           f"--use_cs={'true' if use_cs else 'false'}", "--reg_lambda=0.3", "--seed=99", "--use_pp=true", "--iters=2"],
+                          stdout=subprocess.DEVNULL)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_img(D, 35, 5 if use_cs else 0, 0.3)
+    gpu_ctx.patchmatch(2, seed=99, schedule=0)
+    want = gpu_ctx.postprocess(4)
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "cl.pgm")), want[0])
+    np.testing.assert_array_equal(pngio.read_pnm(str(tmp_path / "cr.pgm")), want[1])
