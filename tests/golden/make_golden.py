@@ -71,9 +71,35 @@ def pipeline_fixture():
     np.savez_compressed(os.path.join(OUT, "pipeline_96x64_d16.npz"), **out)
 
 
+def img_fixture():
+    """GrdPC / CSPC (plane_cost/grd_pc.cc, cspc.cc): 64x48, max_dis 16 -- 600 GetPlaneCost records per view and the final maps of a
+    2-iteration raster run with post-processing."""
+    w, h, D = 64, 48, 16
+    l, r, _, _ = synth.make_pair(w, h, D, regions=3, seed=11)
+    out = dict(l=l, r=r, max_dis=D, dis_scale=4, seed=777)
+    for name, sn, lam in (("grdpc", 0, 0.0), ("cspc", 5, 0.3)):
+        pc = po.PlaneCost(l, r, D, 35, sn, lam, cc="IMG")
+        rng = np.random.default_rng(2025)
+        n = 600
+        for v in (0, 1):
+            xy, norm, point, param = random_planes(rng, n, w, h, D)
+            out[f"{name}_v{v}_xy"] = xy
+            out[f"{name}_v{v}_np"] = np.concatenate([norm, param], 1)
+            out[f"{name}_v{v}_serial"] = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], v, po.SUM_SERIAL) for i in range(n)])
+            out[f"{name}_v{v}_device"] = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], v, po.SUM_DEVICE) for i in range(n)])
+        pm = po.PatchMatch(l, r, D, 4)
+        pm.run(2, pc, False, seed=777, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+        out[f"{name}_dis"] = np.stack([pm.dis(v) for v in (0, 1)])
+        out[f"{name}_plane_sha"] = np.array([sha(np.concatenate([pm.planes(v)[..., 0:3], pm.planes(v)[..., 6:9]], -1)) for v in (0, 1)])
+        pm.postprocess()
+        out[f"{name}_pp"] = np.stack([pm.dis(v) for v in (0, 1)])
+    np.savez_compressed(os.path.join(OUT, "imgcost_64x48_d16.npz"), **out)
+
+
 if __name__ == "__main__":
     cost_fixture()
     pipeline_fixture()
+    img_fixture()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

@@ -120,3 +120,25 @@ def test_good_disparities_on_a_synthetic_pair(gpu_ctx, mid_pair):
         gt = mid_pair["gl"]
         m = np.s_[4:-4, mid_pair["max_dis"] + 4:-4]
         assert np.mean(np.abs(d[m] - gt[m]) > 1.0) < 0.25  # raw left disparities, occlusions included, no post-processing
+
+
+def test_golden_fixture(gpu_ctx):
+    """the committed answer (tests/golden/imgcost_64x48_d16.npz, made by tests/golden/make_golden.py from the oracle)"""
+    import hashlib
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "imgcost_64x48_d16.npz"))
+    for name, sn, lam in (("grdpc", 0, 0.0), ("cspc", 5, 0.3)):
+        gpu_ctx.set_images(g["l"], g["r"])
+        gpu_ctx.build_cost_img(int(g["max_dis"]), 35, sn, lam)
+        for v in (0, 1):
+            got = gpu_ctx.plane_cost_batch(v, g[f"{name}_v{v}_xy"], g[f"{name}_v{v}_np"])
+            np.testing.assert_array_equal(got, g[f"{name}_v{v}_device"])
+            np.testing.assert_allclose(got, g[f"{name}_v{v}_serial"], rtol=1e-12, atol=0)
+        gpu_ctx.patchmatch(2, seed=int(g["seed"]), schedule=po.SCHED_RASTER)
+        for v in (0, 1):
+            np.testing.assert_array_equal(gpu_ctx.disparity_u8(v, int(g["dis_scale"])), g[f"{name}_dis"][v])
+            npar, _ = gpu_ctx.get_planes(v)
+            assert hashlib.sha256(np.ascontiguousarray(npar).tobytes()).hexdigest() == str(g[f"{name}_plane_sha"][v])
+        l, r = gpu_ctx.postprocess(int(g["dis_scale"]))
+        np.testing.assert_array_equal(l, g[f"{name}_pp"][0])
+        np.testing.assert_array_equal(r, g[f"{name}_pp"][1])
