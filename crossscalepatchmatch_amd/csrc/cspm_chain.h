@@ -267,6 +267,9 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // every tap is computed once).  Work split: cross-scale -> one wave per pyramid level; single-scale -> one wave per
 // chain pass.  No early exit: both candidate costs are needed in full when accepted.
 // ------------------------------------------------------------------------------------------------
+#ifndef CSPM_SWEEP_PRIO
+#define CSPM_SWEEP_PRIO 3
+#endif
 #ifndef CSPM_SWEEP_WPL
 #define CSPM_SWEEP_WPL 1
 #endif
@@ -485,6 +488,11 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
   __shared__ unsigned int s_item;
   __shared__ int s_ok;
   const Luts lut = load_luts(cd, sh.lut);
+#if CSPM_SWEEP_PRIO
+  // The sweep is a chain of 1 616 dependent pixel evaluations with few waves: when it shares SIMDs with the throughput kernels
+  // of other pairs in flight, its instructions go first.
+  __builtin_amdgcn_s_setprio(CSPM_SWEEP_PRIO);
+#endif
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int ndiag = pm.W + pm.H - 1;

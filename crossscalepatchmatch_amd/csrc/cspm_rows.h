@@ -53,15 +53,35 @@ __device__ __forceinline__ typename StripReg<SRC>::type ld_strip(const char *row
 // its second, one ds_read_b64 of the neighbouring slot the second gradient -- 24 bytes in two LDS instructions at the
 // full 256 B/clk (12-byte ds_read_b96 would run at 96 B/clk, 8-byte reads of 16-byte slots use half the banks).
 // (GrdPC / CSPC: slot k carries the colour of column k+1 for both views -- a tap reads columns fx and fx+1.)
+// LDS is addressed with plain 32-bit byte addresses (lds_ld): a tap's address is then ONE integer operation on top of the
+// per-row lane constant, every other displacement is an instruction immediate (through generic pointers the compiler re-adds
+// the strip base per tap and cannot fold negative displacements).
+typedef __attribute__((address_space(3))) const char lds_cchar;
+__device__ __forceinline__ int lds_addr(const void *p) { return (int)(uintptr_t)(lds_cchar *)p; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T> struct LdsVec { typedef T type; };
+template <> struct LdsVec<uint2> { typedef u32x2 type; };
+template <> struct LdsVec<uint4> { typedef u32x4 type; };
+template <class T>
+__device__ __forceinline__ T lds_ld(int adr) {
+  typedef typename LdsVec<T>::type V;
+  const V v = *(__attribute__((address_space(3))) const V *)(uintptr_t)(unsigned)adr;
+  if constexpr (sizeof(T) == 16) return T{v[0], v[1], v[2], v[3]};
+  else if constexpr (sizeof(T) == 8) return T{v[0], v[1]};
+  else return v;
+}
+// `adr`: LDS address of the LOWER of the two slots a tap reads (left view, GRD / census: slot of x-f-1; otherwise the first cell)
 template <int SRC, int VIEW>
-__device__ __forceinline__ void rd_cells(const char *strip, int adr, uint4 &o0, uint4 &o1) {
-  constexpr int dirS = (VIEW == 0 && SRC != kSrcImg) ? -16 : 16;
+__device__ __forceinline__ void rd_cells(int adr, uint4 &o0, uint4 &o1) {
+  constexpr bool down = VIEW == 0 && SRC != kSrcImg;  // second cell one slot below the first
+  constexpr int a0 = down ? 16 : 0, a1 = down ? 0 : 16;
   if constexpr (SRC == kSrcCen) {
-    o0 = *reinterpret_cast<const uint4 *>(strip + adr);
-    o1 = *reinterpret_cast<const uint4 *>(strip + adr + dirS);
+    o0 = lds_ld<uint4>(adr + a0);
+    o1 = lds_ld<uint4>(adr + a1);
   } else {
-    const uint4 s0 = *reinterpret_cast<const uint4 *>(strip + adr);
-    const uint2 g1 = *reinterpret_cast<const uint2 *>(strip + adr + dirS);
+    const uint4 s0 = lds_ld<uint4>(adr + a0);
+    const uint2 g1 = lds_ld<uint2>(adr + a1);
     o0 = uint4{s0.x, s0.y, s0.z, 0u};
     o1 = uint4{g1.x, g1.y, s0.w, 0u};
   }
@@ -83,13 +103,13 @@ __device__ __forceinline__ StageReg<SRC> ld_stage(const char *row, int byte_off)
 // own-view strip: element of window column dx of a lane.  GRD / volumes: adr_g addresses the gradient array (8-byte stride),
 // adr_p the colour array (4-byte stride) -- consecutive lanes hit consecutive banks; census: adr_g addresses 16-byte slots.
 template <int SRC>
-__device__ __forceinline__ uint4 rd_own(const char *ostrip, int adr_g, int adr_p, int j) {
+__device__ __forceinline__ uint4 rd_own(int adr_g, int adr_p, int j) {
   if constexpr (SRC == kSrcCen) {
-    return *reinterpret_cast<const uint4 *>(ostrip + adr_g + j * 16);
+    return lds_ld<uint4>(adr_g + j * 16);
   } else {
-    const uint32_t pix = *reinterpret_cast<const uint32_t *>(ostrip + adr_p + j * 4);
+    const uint32_t pix = lds_ld<uint32_t>(adr_p + j * 4);
     uint2 g{0u, 0u};
-    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) g = *reinterpret_cast<const uint2 *>(ostrip + adr_g + j * 8);
+    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) g = lds_ld<uint2>(adr_g + j * 8);
     return uint4{g.x, g.y, pix, 0u};
   }
 }
@@ -153,8 +173,8 @@ struct RowTree {
 
 // where the taps of one window row find their operands
 struct RowSrc {
-  // staged: LDS byte addresses of window column 0 of the lane (other strip at f = 0; own strip gradient / colour arrays)
-  const char *strip, *ostrip;
+  // staged: LDS addresses (lds_addr) of window column 0 of the lane: other strip at f = 0 (biased one slot down for the left
+  // view, see rd_cells); own strip gradient / colour arrays
   int adr_o, adr_g, adr_p;
   // unstaged: image rows in global memory and the byte offset of the lane's window column 0
   const char *own_row, *oth_row;
@@ -189,7 +209,7 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
   bool valid[N], in_img[N];
   // stage 1: own elements
 #pragma unroll
-  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(R.ostrip, adr_g, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
+  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(adr_g, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
   // stage 2: disparities (pure arithmetic), then the cells of the other view
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -204,7 +224,7 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
       valid[k] = g.valid;
       const int fxc = min(max(g.fx, R.fx_lo), R.fx_hi);
       if (STAGED) {
-        rd_cells<SRC, VIEW>(R.strip, fxc * 16 + R.img_base, o0[k], o1[k]);
+        rd_cells<SRC, VIEW>(fxc * 16 + R.img_base, o0[k], o1[k]);
       } else {
         o0[k] = ld_elem<SRC>(R.oth_row, fxc * E + R.img_base);
         o1[k] = ld_elem<SRC>(R.oth_row, fxc * E + R.img_base + E);
@@ -220,7 +240,7 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
       const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
       tmp[k] = d.fw * v[0] + d.fr * v[A.slab];
     } else if (STAGED) {
-      rd_cells<SRC, VIEW>(R.strip, mad_const<dirS>(d.f, adr_o) + j * 16, o0[k], o1[k]);
+      rd_cells<SRC, VIEW>(mad_const<dirS>(d.f, adr_o) + j * 16, o0[k], o1[k]);
     } else {
       const int of = mad_const<dirE>(d.f, off_g);
       o0[k] = ld_elem<SRC>(R.oth_row, of + j * E);
@@ -358,12 +378,12 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   const int o_lo = L.pad + cmin - A.half, o_len = cmax - cmin + 2 * A.half + 1;
   const bool staged = s_len <= ctx.cap && o_len <= ctx.ocap;  // wave-uniform
   RowSrc R;
-  R.strip = ctx.strip; R.ostrip = ctx.ostrip;
-  R.adr_o = (L.pad + cx - A.half - s_lo) * 16;
-  R.adr_g = (cx - cmin) * (SRC == kSrcCen ? 16 : 8);
-  R.adr_p = ctx.ocap * 8 + (cx - cmin) * 4;
+  const int strip_a = lds_addr(ctx.strip), ostrip_a = lds_addr(ctx.ostrip);
+  R.adr_o = strip_a + (L.pad + cx - A.half - s_lo) * 16 - ((VIEW == 0 && SRC != kSrcImg) ? 16 : 0);
+  R.adr_g = ostrip_a + (cx - cmin) * (SRC == kSrcCen ? 16 : 8);
+  R.adr_p = ostrip_a + ctx.ocap * 8 + (cx - cmin) * 4;
   R.lane_off = (L.pad + cx - A.half) * E;
-  R.img_base = staged ? (L.pad - s_lo) * 16 : L.pad * E;
+  R.img_base = staged ? strip_a + (L.pad - s_lo) * 16 : L.pad * E;
   R.fx_lo = staged ? s_lo - L.pad : -L.pad;
   R.fx_hi = staged ? s_hi - 1 - L.pad : L.W + L.pad - 2;
   const uint32_t Ip = SRC == kSrcCen ? L.pc[VIEW][cy * L.Wp + L.pad + cx].pix : L.px[VIEW][cy * L.Wp + L.pad + cx].pix;
