@@ -22,9 +22,15 @@
 
 namespace cspm {
 
-constexpr int kRowWaves = 8;                  // waves per workgroup (they share the two lookup tables)
+#ifndef CSPM_ROW_WAVES
+#define CSPM_ROW_WAVES 4
+#endif
+constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share the two lookup tables)
 #ifndef CSPM_ROW_MINW
-#define CSPM_ROW_MINW 4                       // minimum waves per SIMD the register allocator must leave room for (row kernels)
+#define CSPM_ROW_MINW 3                       // waves per SIMD the register allocator must leave room for: 168 VGPRs.  Measured
+                                              // (C3, ms per k_refine launch): 2 waves 66.1 (211 VGPRs, no spill), 3 waves 55.7,
+                                              // 4 waves 58.3 (128 VGPRs), 5 waves 64.3, 6 waves 67.2; workgroups of 2/3/4/6/8/12
+                                              // waves at 3 per SIMD: 56.0 / 58.4 / 55.7 / 78.9 / - / 63.4
 #endif
 constexpr int kRowBlock = kRowWaves * kWave;
 
