@@ -293,6 +293,12 @@ __device__ __forceinline__ SweepShared sweep_shared(unsigned char *smem) {
 
 // Both candidate costs at pixel (x,y) of view v; every wave of the workgroup calls it.  `both` = the two candidates differ
 // (otherwise only c0 is evaluated and cost1 = cost0).  Results are valid in wave 0 after the call.
+#ifdef CSPM_SWEEP_TRACE
+__shared__ long long *s_tr;  // debug: the 8 stamps of the item this workgroup works on
+#define EVAL_STAMP(slot) do { if (wave == 0 && lane == 0 && s_tr) s_tr[slot] = wall_clock64(); } while (0)
+#else
+#define EVAL_STAMP(slot) do { } while (0)
+#endif
 template <bool CS, int SRC>
 __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, const SweepShared &sh, int v, int x, int y, const Cand &c0,
                                                 const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
@@ -315,8 +321,10 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
         plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
         fill_tabs(m, 1, A, pa, pb, pc, lane);
         wave_lds_fence();
+        EVAL_STAMP(4);
         double S[2][kMaxPasses];
         chain_passes<SRC, 2>(cd, A, lut, m, lane, part_of, kSweepWpl, S);
+        EVAL_STAMP(5);
         if (kSweepWpl > 1) {
           store_parts<2>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
           store_parts<2>(part1, S, 1, lane, part_of, kSweepWpl, A.passes);
@@ -514,6 +522,9 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
     const unsigned int item = s_item;
     if (item >= sw.total) return;
     SWEEP_STAMP(0);
+#ifdef CSPM_SWEEP_TRACE
+    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + (size_t)item * 8 : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; } }
+#endif
     while (k + 1 < ndiag && item >= sw.start[k + 1]) ++k;  // items of one workgroup only increase
     const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
     const int cnt = ys_hi - ys_lo + 1;
@@ -568,8 +579,6 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
         eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0);
       }
     }
-    SWEEP_STAMP(4);
-    SWEEP_STAMP(5);
     // 3. accept (x-predecessor first, then y-predecessor against the updated minimum), publish, raise the flag
     if (wave == 0 && lane == 0) {
       double best_cost = f.cost[i];  // own pixel: nobody else writes it during the sweep

@@ -17,7 +17,13 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cfg, l, r, _, _ = synth.make_config(name)
 ctx = cs.StereoContext(0)
 ctx.set_images(l, r)
-ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+kind = os.environ.get("CSPM_TP_COST", "grd")  # grd | cen | img | grdvol
+if kind == "cen":
+    ctx.build_cost_cen(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+elif kind == "img":
+    ctx.build_cost_img(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+else:
+    ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=kind == "grdvol")
 ctx.patchmatch(1, seed=12345)  # warm-up
 ctx.synchronize()
 ctx.enable_timing(True)
