@@ -173,10 +173,8 @@ int drain_timing(cspm_ctx *c) {
 
 // row engine: one wave per 64-pixel run of an image row, kRowWaves waves per workgroup, grid a multiple of 8 (XCD bands)
 inline unsigned row_grid(int W, int H, int views) {
-  const long long items = (long long)views * H * ((W + kWave - 1) / kWave);
-  long long nb = (items + kRowWaves - 1) / kRowWaves;
-  nb = (nb + 7) / 8 * 8;
-  return (unsigned)nb;
+  const long long per_xcd = (row_items_per_xcd(W, H, views) + kRowWaves - 1) / kRowWaves;  // workgroups per XCD (cspm_rows.h: row_item)
+  return (unsigned)(per_xcd * 8);
 }
 inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
 inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }

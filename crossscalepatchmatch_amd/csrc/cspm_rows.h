@@ -519,20 +519,38 @@ __device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, con
                    : eval_rows_view<CS, SRC, 1>(cd, lut, ctx, x, gen, thresh, use_thresh);
 }
 
-// pixel run of this wave: item = (view, y, 64-pixel segment), XCD-banded.  Returns false past the end.
+// pixel run of this wave: item = (view, y, 64-pixel segment).  Workgroups are dealt round-robin to the 8 XCDs (each with its
+// own L2); the image rows (both views stacked) are cut into blocks of kRowBand rows and XCD k works through blocks k, k+8,
+// k+16, ... in order: what runs on an XCD at any time is ~1.5 blocks of neighbouring rows (window rows are shared in its L2),
+// and every XCD gets the same mix of image top, middle and bottom -- border rows have clipped windows and are cheaper, so
+// contiguous eighths of the image left half of the XCDs idle at the end (measured, CSPM_ROW_BAND).  Returns false past the end.
+#ifndef CSPM_ROW_BAND
+#define CSPM_ROW_BAND 4
+#endif
+constexpr int kRowBand = CSPM_ROW_BAND;
 struct RowItem {
   int v, y, x0;
 };
+__host__ __device__ inline long long row_items_per_xcd(int W, int H, int views) {
+  const int segs = (W + kWave - 1) / kWave;
+  const int nblk = (views * H + kRowBand - 1) / kRowBand;
+  return (long long)((nblk + 7) / 8) * kRowBand * segs;
+}
 __device__ __forceinline__ bool row_item(int W, int H, int views, RowItem &it) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int segs = (W + kWave - 1) / kWave;
-  const long long e = xcd_block() * kRowWaves + wave;
-  if (e >= (long long)views * H * segs) return false;
-  const int per_view = H * segs;
-  it.v = (int)(e / per_view);
-  const int r = (int)(e - (long long)it.v * per_view);
-  it.y = r / segs;
-  it.x0 = (r - it.y * segs) * kWave;
+  const int xcd = (int)(blockIdx.x % 8u);
+  const long long e = (long long)(blockIdx.x / 8u) * kRowWaves + wave;  // index among this XCD's waves
+  if (e >= row_items_per_xcd(W, H, views)) return false;
+  const int per_blk = kRowBand * segs;
+  const int blk_local = (int)(e / per_blk);
+  const int rem = (int)(e - (long long)blk_local * per_blk);
+  const int row_in_blk = rem / segs;
+  const int row = (blk_local * 8 + xcd) * kRowBand + row_in_blk;  // row of the stacked views
+  if (row >= views * H) return false;
+  it.v = row / H;
+  it.y = row - it.v * H;
+  it.x0 = (rem - row_in_blk * segs) * kWave;
   return true;
 }
 
