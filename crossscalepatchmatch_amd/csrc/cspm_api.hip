@@ -51,7 +51,10 @@ enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2, kKindImg = 3 };
 
 struct cspm_ctx {
   int device = 0, ncu = 256;
-  int sweep_wg_per_cu = 3;  // persistent sweep: workgroups launched per CU (tuning knob, env CSPM_SWEEP_WG)
+  // persistent sweep: workgroups launched per CU (env CSPM_SWEEP_WG).  2..6 take the same time when the pair is alone (the sweep
+  // is bound by its dependency chain; 1 is 43 % slower); the resident workgroups mostly wait, and every one of them holds
+  // registers another pair's refinement could use: with three pairs in flight 2 gives 222.7 ms per pair, 3 gives 228.1.
+  int sweep_wg_per_cu = 2;
   int refine_chunk = 64;  // PlaneRefinement halving steps per launch (tuning knob, env CSPM_REFINE_CHUNK)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
