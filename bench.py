@@ -245,11 +245,11 @@ def main():
                     "frac": winstr / avg_s / peak,
                     "traffic": pmc["hbm_bytes_per_launch"], "hbm_frac_of_peak": pmc["hbm_bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS,
                     "lds_busy_frac_pmc": pmc["lds_busy_frac"], "valu_winstr_per_64_algorithmic_taps": winstr / (alg_taps * steps_per_launch / 64),
-                    "note": "The tap stream is served on chip (HBM traffic is a fraction of a percent of the algorithmic bytes), so the "
+                    "note": "The tap stream is served on chip (measured HBM traffic is %.1f %% of the algorithmic bytes), so the "
                             "bound is not HBM.  bound = VALU issue: achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of "
                             "the same command, profiles/r02_refine_pmc.json) / the launch time measured here; peak = 1024 SIMDs x shader "
                             "clock / 4.1 cycles per wave-instruction (tools/ubench/valu_issue.hip).  The LDS (strips + tables) is the "
-                            "second resource, lds_busy_frac_pmc.",
+                            "second resource, lds_busy_frac_pmc." % (100.0 * pmc["hbm_bytes_per_launch"] / alg_bytes),
                 })
             else:
                 roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": None,
