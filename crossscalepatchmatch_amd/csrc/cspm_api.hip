@@ -90,7 +90,8 @@ struct cspm_ctx {
   uint8_t *d_dis[2] = {nullptr, nullptr};
   int *d_valid[2] = {nullptr, nullptr};
   // persistent raster sweep (k_spatial_sweep)
-  unsigned int *d_sweep_ctrl = nullptr, *d_sweep_done = nullptr, *d_sweep_start = nullptr;
+  unsigned int *d_sweep_ctrl = nullptr, *d_sweep_start = nullptr;
+  unsigned long long *d_sweep_gran = nullptr;  // persistent sweep: 12 data-tagged granules per pixel and view (cspm_chain.h)
   unsigned int sweep_epoch = 0;
   long long opt_raster_launches = 0;  // CSPM_OPT_RASTER_LAUNCHES
   bool sweep_pending = false;         // a sweep's error word has not been checked yet
@@ -211,9 +212,10 @@ void free_field(cspm_ctx *c) {
     c->d_valid[v] = nullptr;
   }
   if (c->d_sweep_ctrl) (void)hipFree(c->d_sweep_ctrl);
-  if (c->d_sweep_done) (void)hipFree(c->d_sweep_done);
+  if (c->d_sweep_gran) (void)hipFree(c->d_sweep_gran);
   if (c->d_sweep_start) (void)hipFree(c->d_sweep_start);
-  c->d_sweep_ctrl = c->d_sweep_done = c->d_sweep_start = nullptr;
+  c->d_sweep_ctrl = c->d_sweep_start = nullptr;
+  c->d_sweep_gran = nullptr;
   c->field_mem = nullptr;
   c->vc = ViewCand{nullptr, nullptr, nullptr};
   c->field_alloc = false;
@@ -462,11 +464,11 @@ int ensure_field(cspm_ctx *c) {
     if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
   }
-  // persistent sweep state: control words, per-pixel done epochs (zero = never), diagonal start table
+  // persistent sweep state: control words, per-pixel granules (tag zero = never written), diagonal start table
   if ((rc = dalloc(c, &c->d_sweep_ctrl, 2, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
-  if ((rc = dalloc(c, &c->d_sweep_done, 2 * n, nullptr))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_sweep_done, 0, sizeof(unsigned int) * 2 * n, c->stream));
+  if ((rc = dalloc(c, &c->d_sweep_gran, 2 * n * kGranPerPixel, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_gran, 0, sizeof(unsigned long long) * 2 * n * kGranPerPixel, c->stream));
   c->sweep_epoch = 0;
   {
     const int nd = c->W + c->H - 1;
@@ -569,8 +571,8 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     // one persistent launch per sweep: 2 workgroups of 8 waves per CU pull pixels in diagonal-major order
     Sweep sw{};
     sw.ctrl = c->d_sweep_ctrl;
-    sw.done[0] = c->d_sweep_done;
-    sw.done[1] = c->d_sweep_done + (size_t)c->W * c->H;
+    sw.gran[0] = c->d_sweep_gran;
+    sw.gran[1] = c->d_sweep_gran + (size_t)c->W * c->H * kGranPerPixel;
     sw.start = c->d_sweep_start;
     sw.epoch = ++c->sweep_epoch;
     sw.total = 2u * (unsigned)c->W * (unsigned)c->H;

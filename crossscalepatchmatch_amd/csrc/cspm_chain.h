@@ -443,18 +443,22 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd,
 // instead of for a kernel boundary.  Dataflow instead of W+H-2 launches per sweep: a pixel starts as
 // soon as ITS predecessors are final, diagonals overlap, and the fixed cost per launch is gone.
 //
-// Inter-workgroup protocol (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1 never
-// refreshed by other CUs' stores): every word another workgroup may read -- the 7 doubles of a plane
-// and the done flag -- is written with 8-byte / 4-byte AGENT-scope atomic stores (write-through) and
-// read with agent-scope atomic loads (L1 bypass), both sides; the producer drains its stores
-// (s_waitcnt vmcnt(0)) before it stores the flag.  No fences, no reliance on placement or dispatch
-// order.  Deadlock freedom: pixels are claimed in an order in which predecessors come first, so every
-// flag a workgroup waits for belongs to a pixel already claimed by a running workgroup.  Every spin is
-// bounded (wall clock); a timeout raises ctrl[1] and all workgroups drain.
+// Inter-workgroup protocol (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1 never refreshed by other
+// CUs' stores): a pixel hands its FINAL plane to its two successors as 12 data-tagged granules -- naturally aligned 8-byte
+// words {32 bits of the plane's six doubles, epoch of this sweep}, each written by ONE agent-scope (write-through) store and
+// read by agent-scope (L1-bypassing) loads.  The consumer polls the granules themselves: when all tags carry the epoch it
+// already holds the data -- no separate flag, no producer-side drain, no second round trip (a flag + payload hand-over
+// costs 1.7-1.9x a granule hand-over on this chip).  8-byte accesses are single-copy atomic, so a granule is never torn and
+// needs no ordering against the others.  No fences, no reliance on placement or dispatch order.  Deadlock freedom: pixels
+// are claimed in an order in which predecessors come first, so every granule a workgroup waits for belongs to a pixel
+// already claimed by a running workgroup.  Every spin is bounded (wall clock); a timeout raises ctrl[1] and all workgroups
+// drain.  The plane field itself (what later kernels read) is written with plain stores: nobody reads it across workgroups
+// inside the sweep except its owner.
 // ------------------------------------------------------------------------------------------------
+constexpr int kGranPerPixel = 12;
 struct Sweep {
   unsigned int *ctrl;         // [0] next item, [1] error (sticky)
-  unsigned int *done[2];      // per view, per pixel: epoch of the last sweep that finalised the pixel
+  unsigned long long *gran[2];  // per view, per pixel: kGranPerPixel data-tagged granules {32 bits of the final plane, epoch}
   const unsigned int *start;  // start[k] = items (both views) on diagonals < k; W+H entries
   unsigned int epoch, total;
   long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
@@ -473,10 +477,15 @@ __device__ __forceinline__ void st_agent(double *p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool wait_done(const unsigned int *flag, unsigned int epoch, unsigned int *err) {
+// lanes 0..23 of one wave: lane l polls granule l % 12 of predecessor l / 12 (`need` false: nothing to wait for).  Returns the
+// wave-uniform verdict; on success `g` holds the lane's granule.
+__device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool need, unsigned int epoch, unsigned int *err, unsigned long long &g) {
   const long long t0 = wall_clock64();
+  g = 0ull;
   for (unsigned spins = 1;; ++spins) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    if (need) g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ready = !need || (unsigned int)(g >> 32) == epoch;
+    if (__builtin_amdgcn_ballot_w64(!ready) == 0ull) return true;
     __builtin_amdgcn_s_sleep(1);
     if ((spins & 255u) == 0u) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
@@ -537,27 +546,26 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
     const long long jx = i - inc, jy = i - (long long)inc * pm.W;
     const bool have0 = xs > 0, have1 = ys > 0;
     SWEEP_STAMP(1);
-    // 1. wait for the predecessors: lanes 0 and 1 of wave 0 poll one flag each
-    if (wave == 0 && lane < 2) {
-      const bool need = lane == 0 ? have0 : have1;
-      if (need && !wait_done(sw.done[v] + (lane == 0 ? jx : jy), sw.epoch, &sw.ctrl[1])) s_ok = 0;
+    // 1. wait for the predecessors' planes: lanes 0..23 of wave 0 poll one granule each; the data arrives with the tags
+    if (wave == 0) {
+      const int pred = lane >= kGranPerPixel ? 1 : 0, part = lane - pred * kGranPerPixel;
+      const bool need = lane < 2 * kGranPerPixel && (pred == 0 ? have0 : have1);
+      unsigned long long g;
+      const bool ok = wait_granules(sw.gran[v] + (pred == 0 ? jx : jy) * kGranPerPixel + (need ? part : 0), need, sw.epoch, &sw.ctrl[1], g);
+      if (lane < 2 * kGranPerPixel) reinterpret_cast<uint32_t *>(&s_plane[0][0])[lane] = (uint32_t)g;  // s_plane[pred][part / 2], half part % 2
+      if (lane == 0 && !ok) s_ok = 0;
     }
     __syncthreads();
     if (!s_ok) return;
-    asm volatile("" ::: "memory");
     SWEEP_STAMP(2);
     // 2. both candidate costs in one pass over the window
     double cost0 = 0.0, cost1 = 0.0;
     bool eval0 = false, eval1 = false;
     if (have0 || have1) {
       // with one candidate missing, both slots hold the existing one (the duplicate is computed once)
-      const long long j0 = have0 ? jx : jy, j1 = have1 ? jy : jx;
-      const Cand c0{ld_agent(f.nx + j0), ld_agent(f.ny + j0), ld_agent(f.nz + j0), ld_agent(f.a + j0), ld_agent(f.b + j0), ld_agent(f.c + j0)};
-      const Cand c1{ld_agent(f.nx + j1), ld_agent(f.ny + j1), ld_agent(f.nz + j1), ld_agent(f.a + j1), ld_agent(f.b + j1), ld_agent(f.c + j1)};
-      if (wave == 0 && lane == 0) {
-        s_plane[0][0] = c0.nx; s_plane[0][1] = c0.ny; s_plane[0][2] = c0.nz; s_plane[0][3] = c0.a; s_plane[0][4] = c0.b; s_plane[0][5] = c0.c;
-        s_plane[1][0] = c1.nx; s_plane[1][1] = c1.ny; s_plane[1][2] = c1.nz; s_plane[1][3] = c1.a; s_plane[1][4] = c1.b; s_plane[1][5] = c1.c;
-      }
+      const int p0 = have0 ? 0 : 1, p1 = have1 ? 1 : 0;
+      const Cand c0{s_plane[p0][0], s_plane[p0][1], s_plane[p0][2], s_plane[p0][3], s_plane[p0][4], s_plane[p0][5]};
+      const Cand c1{s_plane[p1][0], s_plane[p1][1], s_plane[p1][2], s_plane[p1][3], s_plane[p1][4], s_plane[p1][5]};
       // Result-preserving shortcuts (no arithmetic skipped that could change an outcome):
       //  * both predecessors hold bitwise the same plane (very common once the sweep has passed over them): the second
       //    evaluation would return the bits of the first and `cost1 < min(cur, cost0)` would fail;
@@ -579,20 +587,26 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
         eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0);
       }
     }
-    // 3. accept (x-predecessor first, then y-predecessor against the updated minimum), publish, raise the flag
-    if (wave == 0 && lane == 0) {
+    // 3. accept (x-predecessor first, then y-predecessor against the updated minimum; :198-212), publish the FINAL plane.
+    //    cost0 / cost1 are uniform in wave 0, so every lane of it takes the same decision.
+    if (wave == 0) {
       double best_cost = f.cost[i];  // own pixel: nobody else writes it during the sweep
       int pick = -1;
       if (eval0 && cost0 < best_cost) { best_cost = cost0; pick = 0; }
       if (eval1 && cost1 < best_cost) { best_cost = cost1; pick = 1; }
-      if (pick >= 0) {
-        st_agent(f.nx + i, s_plane[pick][0]); st_agent(f.ny + i, s_plane[pick][1]); st_agent(f.nz + i, s_plane[pick][2]);
-        st_agent(f.a + i, s_plane[pick][3]); st_agent(f.b + i, s_plane[pick][4]); st_agent(f.c + i, s_plane[pick][5]);
-        st_agent(f.cost + i, best_cost);
-      }
       SWEEP_STAMP(6);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the plane is in memory before the flag can be seen
-      __hip_atomic_store(sw.done[v] + i, sw.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long comp = f.ny - f.nx;  // the six components of a view's plane field are equally spaced arrays
+      if (lane < kGranPerPixel) {
+        const int k = lane >> 1;
+        const double val = pick >= 0 ? s_plane[pick][k] : f.nx[k * comp + i];
+        const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(val) : (unsigned int)__double2loint(val);
+        __hip_atomic_store(sw.gran[v] + (size_t)i * kGranPerPixel + lane, ((unsigned long long)sw.epoch << 32) | half, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (pick >= 0) {  // the plane field, for the kernels after the sweep
+        if (lane < 6) f.nx[lane * comp + i] = s_plane[pick][lane];
+        if (lane == 6) f.cost[i] = best_cost;
+      }
       SWEEP_STAMP(7);
     }
     __syncthreads();  // s_item / s_plane / scratch are reused by the next item
