@@ -80,7 +80,7 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * and read them. */
 #define CSPM_OPT_GRD_VOLUMES 1
 /* CSPM_OPT_RASTER_LAUNCHES: 0 (default) = the reference-order raster sweep runs as ONE persistent launch whose
- * workgroups hand pixels over through per-pixel done flags; 1 = one launch per anti-diagonal (W+H-2 launches
+ * workgroups hand pixels over through per-pixel data-tagged granules (the final plane, polled directly); 1 = one launch per anti-diagonal (W+H-2 launches
  * per sweep; same results, kept as a cross-check). */
 #define CSPM_OPT_RASTER_LAUNCHES 2
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
