@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--volumes", action="store_true", help="materialise f64 cost volumes (reference data flow) instead of fused cells")
     ap.add_argument("--raster-launches", action="store_true", help="raster sweep as one launch per anti-diagonal instead of the persistent kernel")
-    ap.add_argument("--cc", default="GRD", choices=["GRD", "CEN"], help="cost function (BASELINE.json's metric is GRD; CEN for comparison)")
+    ap.add_argument("--cc", default="GRD", choices=["GRD", "CEN", "IMG"],
+                    help="cost function (BASELINE.json's metric is GRD; CEN = census; IMG = the volume-free GrdPC / CSPC plane costs, for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket launches with hipEvents")
     args = ap.parse_args()
@@ -156,7 +157,10 @@ def main():
     def step(k):
         ctx, out = ctxs[k % nfl], d_out[k % nfl]  # everything below is enqueued on the context's stream, nothing waits
         ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
-        (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
+        if args.cc == "IMG":
+            ctx.build_cost_img(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+        else:
+            (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
         ctx.patchmatch(3, **pm_kw)
         for v in (0, 1):
             ctx.disparity_u8_device(v, cfg["dis_scale"], out[v].data_ptr())

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd,
 
 // ------------------------------------------------------------------------------------------------
 // The same raster sweep as ONE persistent launch (default): workgroups pull pixels in diagonal-major
-// order from a device-wide counter and wait, per pixel, for the "done" flags of its two predecessors
+// order from a device-wide counter and wait, per pixel, for the final planes of its two predecessors
 // instead of for a kernel boundary.  Dataflow instead of W+H-2 launches per sweep: a pixel starts as
 // soon as ITS predecessors are final, diagonals overlap, and the fixed cost per launch is gone.
 //
@@ -469,14 +469,6 @@ struct Sweep {
 #define SWEEP_STAMP(slot) do { } while (0)
 #endif
 
-__device__ __forceinline__ double ld_agent(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_agent(double *p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
 // lanes 0..23 of one wave: lane l polls granule l % 12 of predecessor l / 12 (`need` false: nothing to wait for).  Returns the
 // wave-uniform verdict; on success `g` holds the lane's granule.
 __device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool need, unsigned int epoch, unsigned int *err, unsigned long long &g) {
