@@ -50,3 +50,17 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cc", ".cpp", ".c", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "cspm_oracle" not in txt and "libcspm_oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    """bench.py has no CPU path either: without a visible GPU it must exit non-zero with a message, for any --gpus."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--gpus", "2"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"] + extra, capture_output=True, timeout=600)
+        assert p.returncode != 0
+        assert b"needs a GPU" in p.stderr + p.stdout
