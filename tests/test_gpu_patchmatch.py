@@ -288,3 +288,31 @@ def test_device_resident_io_stream_and_timing(gpu_ctx, small_pair):
         ctx.set_stream(0)
     finally:
         ctx.close()
+
+
+def test_pairs_in_flight_do_not_interfere(gpu_ctx, small_pair, mid_pair, odd_pair):
+    """bench.py keeps three pairs in flight on one GPU (three contexts, three streams, kernels overlapping on the device; the
+    persistent sweeps of different contexts spin next to each other).  Every context must produce what it produces alone."""
+    import crossscalepatchmatch_amd as cs
+    pairs = [small_pair, mid_pair, odd_pair]
+    alone = []
+    for p in pairs:
+        gpu_ctx.set_images(p["l"], p["r"])
+        gpu_ctx.build_cost_grd(p["max_dis"], 35, 5, 0.3)
+        gpu_ctx.patchmatch(3, seed=5, schedule=po.SCHED_RASTER)
+        alone.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+    ctxs = [cs.StereoContext(0) for _ in pairs]
+    try:
+        for rep in range(2):  # the second round reuses every buffer and the next sweep epochs
+            for c, p in zip(ctxs, pairs):  # everything is enqueued, nothing waits
+                c.set_images(p["l"], p["r"])
+                c.build_cost_grd(p["max_dis"], 35, 5, 0.3)
+                c.patchmatch(3, seed=5, schedule=po.SCHED_RASTER)
+            for c, want in zip(ctxs, alone):
+                for v in (0, 1):
+                    npar, cost = c.get_planes(v)
+                    np.testing.assert_array_equal(npar, want[v][0])
+                    np.testing.assert_array_equal(cost, want[v][1])
+    finally:
+        for c in ctxs:
+            c.close()
