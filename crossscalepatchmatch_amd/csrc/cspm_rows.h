@@ -32,6 +32,12 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
                                               // 4 waves 58.3 (128 VGPRs), 5 waves 64.3, 6 waves 67.2; workgroups of 2/3/4/6/8/12
                                               // waves at 3 per SIMD: 56.0 / 58.4 / 55.7 / 78.9 / - / 63.4
 #endif
+#ifndef CSPM_VIEW_MINW
+#define CSPM_VIEW_MINW CSPM_ROW_MINW
+#endif
+#ifndef CSPM_INIT_MINW
+#define CSPM_INIT_MINW CSPM_ROW_MINW
+#endif
 constexpr int kRowBlock = kRowWaves * kWave;
 
 // Two wave-private LDS strips per window row (sized by strip_capacity / own_capacity, carved from the launch's dynamic LDS):
@@ -585,7 +591,7 @@ __device__ __forceinline__ RowPlane init_plane(const Pm &pm, int v, int x, int y
 }
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_INIT_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
@@ -694,7 +700,7 @@ __device__ __forceinline__ ViewProposal view_proposal(const Pm &pm, int v, int x
 }
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap, int ocap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
