@@ -6,15 +6,14 @@
 //
 // Why lanes = pixels.  With lanes = taps (cspm_chain.h) every tap costs three gathers through the CU's L1 address path
 // (own element, two of the other view) and that path, not arithmetic, bounds the kernel.  Here
-//   * the own-view element of tap dx is ONE coalesced 768-byte row run for the whole wave (lane L reads column
-//     x0+L+dx): scalar base + lane offset + an immediate, no address arithmetic;
-//   * the other view's row is staged once per window row into a wave-private LDS strip ([cx_min-half-D, cx_max+half]
-//     for the left view): every tap of every lane reads its two neighbouring cells from the strip with one address
-//     computation, however incoherent the 64 planes are (random initialisation, early refinement steps);
+//   * both views' rows are staged once per window row into wave-private LDS strips (other view: [cx_min-half-D, cx_max+half]
+//     for the left view; own view: [cx_min-half, cx_max+half]): every tap of every lane reads its operands from the strips
+//     with one address computation, however incoherent the 64 planes are (random initialisation, early refinement steps);
+//     the global loads that fill the strips are coalesced row runs, one window row ahead of the taps;
 //   * rows and columns outside the image cost nothing (rows are skipped by scalar control flow; only waves that touch
 //     the image border carry the per-tap column mask);
 //   * the running sums are registers of the lane: no cross-lane reduction, no per-level table set-up.
-// Per tap and lane: ~30 VALU instructions (19 of them f64), 1 global load, 2 LDS strip reads, 3 LDS table reads.
+// Per tap and lane: 33.3 VALU instructions (19 of them f64) and 7 LDS reads, no global load.
 #pragma once
 #include "cspm_tap.h"
 
