@@ -811,7 +811,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
     const long long cells = (long long)L.W * L.H * (L.D + 1);
     for (int v = 0; v < 2; ++v) {
       Timed t(c, CSPM_K_GRD, 0);
-      hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(stride_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
+      hipLaunchKernelGGL((k_grd_volume<SrcU32, true>), dim3(stride_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
                          SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, 0, L.D + 1, v,
                          (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
     }
@@ -1016,7 +1016,7 @@ int cspm_get_cost_slab(cspm_ctx *c, int view, int level, int d, double *out) {
     hipLaunchKernelGGL(k_cen_volume, dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, c->cen_code[0][level], c->cen_code[1][level], L.W,
                        L.H, d, 1, view, tmp, (unsigned long long *)nullptr);
   else
-  hipLaunchKernelGGL(k_grd_volume<SrcU32>, dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
+  hipLaunchKernelGGL((k_grd_volume<SrcU32, true>), dim3(stride_grid((long long)px)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
                      SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, d, 1, view, tmp,
                      (unsigned long long *)nullptr);
   hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * px, hipMemcpyDeviceToHost, c->stream);
@@ -1067,7 +1067,7 @@ int cspm_grd_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
     return done(fail(c, CSPM_ERR_HIP, "upload failed"));
   hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dl, w}, w, h, w, 0, gl);
   hipLaunchKernelGGL(k_gradient<SrcF64>, dim3(ew_grid((long long)px)), dim3(256), 0, c->stream, SrcF64{dr, w}, w, h, w, 0, gr);
-  hipLaunchKernelGGL(k_grd_volume<SrcF64>, dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, SrcF64{dl, w}, SrcF64{dr, w},
+  hipLaunchKernelGGL((k_grd_volume<SrcF64, false>), dim3(stride_grid((long long)px * maxDis)), dim3(256), 0, c->stream, SrcF64{dl, w}, SrcF64{dr, w},
                      gl, gr, w, 0, w, h, 0, maxDis, right_view, vol, key);
   if (hipMemcpyAsync(vol_out, vol, sizeof(double) * px * maxDis, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -1336,6 +1336,16 @@ int cspm_debug_alive(unsigned long long *out16, int reset) {
   unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cspm::g_alive), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_alive), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  return CSPM_OK;
+}
+#endif
+
+#ifdef CSPM_ROW_STATS
+// debug build only (tools/row_stats.py): the row-engine statistics of cspm_rows.h g_rowstat
+int cspm_debug_rowstats(unsigned long long *out1024, int reset) {
+  static unsigned long long z[16 * 8 * 8];
+  if (hipMemcpyFromSymbol(out1024, HIP_SYMBOL(cspm::g_rowstat), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_rowstat), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
   return CSPM_OK;
 }
 #endif

@@ -8,10 +8,8 @@
 // inside the image get lanes (levels 3-4 of a KITTI pyramid are shorter than the window: no masked rows), so a 35x35
 // window takes ceil(rows/9) <= 4 passes of 5 taps per lane.  A lane's own-view addresses advance by a constant 7
 // elements, the lanes of a row read 7 consecutive elements: row runs, like the window itself.
-// Per pass and candidate the plane enters through two per-wave LDS tables
-//   tabx[dx] = plane_a * q_x            (the product of pre_cs_pc.cc:165)
-//   taby[dy] = plane_b * q_y + plane_c  (q_disp_y, pre_cs_pc.cc:155)
-// so a tap's q_disp is one add -- each entry is rounded exactly like the expression it replaces.
+// A lane's chain j IS the multiplier of the device order's disparity (cspm_tap.h tap_disp): q_disp = fma(a, j, G) with the
+// group base G = fma(a, q_x of the step's first column, q_disp_y) -- two fmas per tap and candidate, no tables.
 // After the passes the chain sums go through LDS once: lane dy adds the 7 partial sums of row dy, and an xor butterfly
 // over the lanes forms the row tree.
 #pragma once
@@ -23,9 +21,10 @@ namespace cspm {
 
 // per-wave LDS scratch of the chain engine
 struct ChainScratch {
-  double tab[2][2][kWave];            // [candidate][x | y][entry]; taps past the window edge read (and discard) stale entries
   double part[kMaxPasses * kWave];    // chain sums of one candidate, pass-major
 };
+// Plane::param() of the candidates of one evaluation at one level
+struct ChainPlane { double a, b, c; };
 
 // everything one level needs, wave-uniform
 struct ChainLevel {
@@ -73,19 +72,11 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
   return A;
 }
 
-// fill candidate c's tables for this level (all lanes of the wave)
-__device__ __forceinline__ void fill_tabs(ChainScratch &m, int c, const ChainLevel &A, double pa, double pb, double pc, int lane) {
-  if (lane < A.n) {
-    m.tab[c][0][lane] = pa * (double)(A.ox0 + lane);
-    m.tab[c][1][lane] = pb * (double)(A.oy0 + lane) + pc;
-  }
-}
-
 // One level, NC candidates (1 or 2) at the same pixel: the plane-independent half of every tap (own element, guide
 // weight) is computed once.  `pass_first/pass_step` let several waves share the passes of one level (single-scale sweep).
 // Chain sums are left in S[c][pass slot]; finish_level() turns them into the level sum.
 template <int SRC, int NC>
-__device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainScratch &m, int lane,
+__device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainPlane (&pl)[NC], int lane,
                                              int pass_first, int pass_step, double S[NC][kMaxPasses]) {
   constexpr int E = elem_size<SRC>();
   const int lutzero = kLutZero;
@@ -103,8 +94,10 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
     const int ob = ((A.oy0 + dy) * A.Wp + A.pad + qx0) * E;  // byte offset of the chain's first tap
     double ty[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) ty[c] = m.tab[c][1][dy];
+    for (int c = 0; c < NC; ++c) ty[c] = pl[c].b * (double)(A.oy0 + dy) + pl[c].c;  // q_disp_y, :155
+    const double jd = (double)j;
     for (int st = 0; st < A.nsteps; ++st) {
+      const double xg = (double)(A.ox0 + kRowMod * st);  // q_x of the group's first column
       const int dx = j + kRowMod * st;
       const bool ok = chain_ok & (dx < A.n) & ((unsigned)(qx0 + kRowMod * st) < (unsigned)A.W);
       const uint4 P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
@@ -113,14 +106,14 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
       const double wgt = lut.w[sad];        // :161-164
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const double q_disp = m.tab[c][0][dx] + ty[c];  // :155,165
+        const double q_disp = tap_disp(pl[c].a, jd, group_disp(pl[c].a, xg, ty[c]));  // :165, device order
         if constexpr (SRC == kSrcImg) {
           const ImgSplit g = split_img(q_disp, A.sgn * q_disp, (double)(qx0 + kRowMod * st), A.Dm1, A.has_valid);
           const int fxc = min(max(g.fx, -A.pad), A.W + A.pad - 2);  // clamps only taps of the "impossible disparity" branch
           const int of = ((A.oy0 + dy) * A.Wp + A.pad + fxc) * E;
           const uint4 o0 = ld_elem<SRC>(A.opx, of), o1 = ld_elem<SRC>(A.opx, of + E);
           const double cell = img_cell(pix_of<SRC>(P), g_of(P), pix_of<SRC>(o0), g_of(o0), pix_of<SRC>(o1), g_of(o1), g.fw);
-          S[c][ps] += wgt * (g.valid ? cell : A.maxc);
+          S[c][ps] = __builtin_fma(wgt, g.valid ? cell : A.maxc, S[c][ps]);
           continue;
         }
         const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
@@ -135,7 +128,7 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           c0 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of));
           c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of + A.dirE));
         }
-        S[c][ps] += tap_value(d, c0, c1, A.maxc, wgt);
+        S[c][ps] = __builtin_fma(wgt, tap_value(d, c0, c1, A.maxc), S[c][ps]);  // :176-177
       }
     }
   }
@@ -182,11 +175,10 @@ __device__ __forceinline__ double eval_plane_chain(const Cost &cd, const Luts &l
     double a = pa, b = pb, c = pc;
     if (CS) plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
     const ChainLevel A = make_chain_level<SRC>(cd, s, view, cur_x, cur_y);
-    wave_lds_fence();  // earlier reads of the tables / part[] are done
-    fill_tabs(m, 0, A, a, b, c, lane);
-    wave_lds_fence();
+    const ChainPlane pl[1] = {{a, b, c}};
     double S[1][kMaxPasses];
-    chain_passes<SRC, 1>(cd, A, lut, m, lane, 0, 1, S);
+    chain_passes<SRC, 1>(cd, A, lut, pl, lane, 0, 1, S);
+    wave_lds_fence();  // earlier reads of part[] are done
     store_parts<1>(m.part, S, 0, lane, 0, 1, A.passes);
     wave_lds_fence();
     const double sc = finish_level(A, m.part, lane);
@@ -311,19 +303,15 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
     int cur_x = x, cur_y = y;
     for (int s = 0; s < level; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
     const ChainLevel A = make_chain_level<SRC>(cd, level < cd.levels ? level : 0, v, cur_x, cur_y);
-    ChainScratch &m = sh.m[wave];
     double *part0 = sh.m[level * kSweepWpl].part, *part1 = sh.m[level * kSweepWpl + (kSweepWpl > 1 ? 1 : 0)].part;
     if (level < cd.levels) {
-      double pa, pb, pc;
-      plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pa, pb, pc);  // :144-149
-      fill_tabs(m, 0, A, pa, pb, pc, lane);
+      ChainPlane pl[2];
+      plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pl[0].a, pl[0].b, pl[0].c);  // :144-149
       if (both) {
-        plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pa, pb, pc);
-        fill_tabs(m, 1, A, pa, pb, pc, lane);
-        wave_lds_fence();
+        plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pl[1].a, pl[1].b, pl[1].c);
         EVAL_STAMP(4);
         double S[2][kMaxPasses];
-        chain_passes<SRC, 2>(cd, A, lut, m, lane, part_of, kSweepWpl, S);
+        chain_passes<SRC, 2>(cd, A, lut, pl, lane, part_of, kSweepWpl, S);
         EVAL_STAMP(5);
         if (kSweepWpl > 1) {
           store_parts<2>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
@@ -339,9 +327,9 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
           if (lane == 0) { sh.lvl[0][level] = s0; sh.lvl[1][level] = s1; }
         }
       } else {
-        wave_lds_fence();
+        const ChainPlane p1[1] = {pl[0]};
         double S[1][kMaxPasses];
-        chain_passes<SRC, 1>(cd, A, lut, m, lane, part_of, kSweepWpl, S);
+        chain_passes<SRC, 1>(cd, A, lut, p1, lane, part_of, kSweepWpl, S);
         store_parts<1>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
         if (kSweepWpl == 1) {
           wave_lds_fence();
@@ -375,20 +363,17 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
     // single scale: the waves share the passes of the one level; chain sums meet in wave 0's scratch
     const int nw = (int)(blockDim.x >> 6);
     const ChainLevel A = make_chain_level<SRC>(cd, 0, v, x, y);
-    ChainScratch &m = sh.m[wave];
-    fill_tabs(m, 0, A, c0.a, c0.b, c0.c, lane);
-    if (both) fill_tabs(m, 1, A, c1.a, c1.b, c1.c, lane);
-    wave_lds_fence();
+    const ChainPlane pl[2] = {{c0.a, c0.b, c0.c}, {c1.a, c1.b, c1.c}};
     double S[2][kMaxPasses];
     if (both) {
-      chain_passes<SRC, 2>(cd, A, lut, m, lane, wave, nw, S);
+      chain_passes<SRC, 2>(cd, A, lut, pl, lane, wave, nw, S);
     } else {
+      const ChainPlane p1[1] = {pl[0]};
       double S1[1][kMaxPasses];
-      chain_passes<SRC, 1>(cd, A, lut, m, lane, wave, nw, S1);
+      chain_passes<SRC, 1>(cd, A, lut, p1, lane, wave, nw, S1);
 #pragma unroll
       for (int ps = 0; ps < kMaxPasses; ++ps) { S[0][ps] = S1[0][ps]; S[1][ps] = S1[0][ps]; }
     }
-    __syncthreads();  // every wave is done reading its tables
     store_parts<2>(sh.m[0].part, S, 0, lane, wave, nw, A.passes);
     store_parts<2>(sh.m[1].part, S, 1, lane, wave, nw, A.passes);
     __syncthreads();

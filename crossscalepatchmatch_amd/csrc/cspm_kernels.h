@@ -319,7 +319,11 @@ __global__ void k_gradient(Src s, int W, int H, int gWp, int gpad, double *__res
 // the volume (pre_cs_pc.cc:75-82).  d0/nd select a slab range (cspm_get_cost_slab in fused mode).
 //   left  view: other = right image at x-d, border branch when x-d < 0     (:88-100)
 //   right view: other = left image at x+d, border branch when x+d >= wid   (:134-147)
-template <class Src>
+// DEV = false: the reference's arithmetic to the last bit (the CCMethod::buildCV boundary, cspm_grd_build_cv_host).
+// DEV = true : the cells of the DEVICE order (cspm_tap.h grd_cell): the final multiply-add is one fma.  These are the cells the
+//              plane cost reads -- recomputed inside the tap engines by default, materialised with CSPM_OPT_GRD_VOLUMES -- and
+//              whose max is max_cost.
+template <class Src, bool DEV>
 __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *__restrict__ lG, const double *__restrict__ rG,
                                                     int gWp, int gpad, int W, int H, int d0, int nd, int right_view,
                                                     double *__restrict__ vol, unsigned long long *max_key) {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *
     double grdDiff = fabs(g0 - og);
     clrDiff = clrDiff > 10.0 ? 10.0 : clrDiff;  // TAU_CLR
     grdDiff = grdDiff > 2.0 ? 2.0 : grdDiff;    // TAU_GRD
-    cost = 0.1 * clrDiff + (1 - 0.1) * grdDiff; // ALPHA
+    cost = DEV ? __builtin_fma(1 - 0.1, grdDiff, 0.1 * clrDiff) : 0.1 * clrDiff + (1 - 0.1) * grdDiff;  // ALPHA
     if (vol) vol[i] = cost;
     best = cost > best ? cost : best;
   }

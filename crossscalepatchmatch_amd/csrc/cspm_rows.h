@@ -38,6 +38,12 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #define CSPM_INIT_MINW CSPM_ROW_MINW
 #endif
 constexpr int kRowBlock = kRowWaves * kWave;
+#ifdef CSPM_ROW_STATS
+// debug (tools/row_stats.py): per phase slot (0 init, 1 view, 2+step refinement), pyramid level and bucket, the number of staged
+// window rows (per wave) whose 64 lanes all take the interpolation branch, bucketed by the number of integer disparities the
+// wave touches on that row (<= 4, 8, 16, 32, more); bucket 5 = rows with some lane outside [1, D); bucket 6 = unstaged rows
+__device__ unsigned long long g_rowstat[16 * 8 * 8];
+#endif
 
 // Two wave-private LDS strips per window row (sized by strip_capacity / own_capacity, carved from the launch's dynamic LDS):
 //   other view: 16-byte slots, see rd_cells();   own view: gradients (8 B) and colours (4 B) as two arrays (GRD, volumes),
@@ -204,9 +210,11 @@ struct RowSrc {
 #ifndef CSPM_ROW_SUB
 #define CSPM_ROW_SUB 2  // taps whose memory round trips are overlapped (sub-batch of a group of 7): register pressure vs latency hiding
 #endif
-template <int SRC, int VIEW, bool EDGE, bool STAGED, int J0, int J1>
+//   ALLV   : every tap of this window row is known to take the interpolation branch in every lane (level_rows decides that per
+//            row from the two end columns): no clamp, no validity test, no select -- 4 instructions per tap less
+template <int SRC, int VIEW, bool EDGE, bool STAGED, bool ALLV, int J0, int J1>
 __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, int adr_o, int adr_g, int adr_p, int off_g,
-                                          uint32_t Ip, double pa, double rowterm, double &qx_d, int e_rel, int e_span, int qy, int cx_lane,
+                                          uint32_t Ip, double pa, double Gg, double qxg_d, int e_rel, int e_span, int qy, int cx_lane,
                                           double S[kRowMod]) {
   constexpr int E = elem_size<SRC>();
   constexpr int dirS = VIEW == 0 ? -16 : 16, dirE = VIEW == 0 ? -E : E;
@@ -225,14 +233,13 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int j = J0 + k;
-    const double q_disp = pa * qx_d + rowterm;  // :165
+    const double q_disp = tap_disp(pa, (double)j, Gg);  // :165, device order (cspm_tap.h)
     in_img[k] = true;
     if (EDGE) in_img[k] = (unsigned)(e_rel + j) <= (unsigned)e_span;
     if constexpr (SRC == kSrcImg) {
-      const ImgSplit g = split_img(q_disp, VIEW == 0 ? -q_disp : q_disp, qx_d, A.Dm1, A.has_valid);  // qx_d: still this tap's column
-      qx_d += 1.0;
+      const ImgSplit g = split_img(q_disp, VIEW == 0 ? -q_disp : q_disp, qxg_d + (double)j, A.Dm1, A.has_valid);  // the tap's column (exact)
       fr[k] = g.fw;
-      valid[k] = g.valid;
+      valid[k] = ALLV ? true : g.valid;
       const int fxc = min(max(g.fx, R.fx_lo), R.fx_hi);
       if (STAGED) {
         rd_cells<SRC, VIEW>(fxc * 16 + R.img_base, o0[k], o1[k]);
@@ -242,14 +249,13 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
       }
       continue;
     }
-    qx_d += 1.0;                                // exact: small integers
-    const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
+    const DispSplit d = ALLV ? split_disp_valid(q_disp) : split_disp(q_disp, A.Dm1, A.has_valid);
     fr[k] = d.fr;
     valid[k] = d.valid;
     if (SRC == kSrcVolume) {
       const int qx = in_img[k] ? cx_lane - A.half + g0 + j : cx_lane;
       const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
-      tmp[k] = d.fw * v[0] + d.fr * v[A.slab];
+      tmp[k] = lerp_cells(d.fr, v[0], v[A.slab]);
     } else if (STAGED) {
       rd_cells<SRC, VIEW>(mad_const<dirS>(d.f, adr_o) + j * 16, o0[k], o1[k]);
     } else {
@@ -275,15 +281,15 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
     for (int k = 0; k < N; ++k) {
       const double c0 = cell_of<SRC>(lut.a, P[k], o0[k]);
       const double c1 = cell_of<SRC>(lut.a, P[k], o1[k]);
-      tmp[k] = (1.0 - fr[k]) * c0 + fr[k] * c1;
+      tmp[k] = lerp_cells(fr[k], c0, c1);
     }
   }
   // stage 5: the "impossible disparity" branch (:166-169), weight (:176), accumulate
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const double maxc = A.maxc;
-    const double t = valid[k] ? tmp[k] : maxc;
-    S[J0 + k] += wgt[k] * t;
+    const double t = (ALLV || valid[k]) ? tmp[k] : maxc;
+    S[J0 + k] = __builtin_fma(wgt[k], t, S[J0 + k]);
   }
 }
 
@@ -293,23 +299,26 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
 //   VIEW   : 0 = left view (other view read at x-f, x-f-1), 1 = right view (x+f, x+f+1)
 //   EDGE   : some lane's window leaves the image in x -> per-tap mask (e_rel = g0 - e_lo per lane, e_span)
 //   STAGED : operands come from the two LDS strips, else from global memory
-template <int SRC, int VIEW, bool EDGE, bool STAGED, int CNT>
+template <int SRC, int VIEW, bool EDGE, bool STAGED, bool ALLV, int CNT>
 __device__ __forceinline__ void tap_group(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, uint32_t Ip, double pa, double rowterm,
-                                          double &qx_d, int e_rel, int e_span, int qy, int cx_lane, double S[kRowMod]) {
+                                          double &qxg_d, int e_rel, int e_span, int qy, int cx_lane, double S[kRowMod]) {
   constexpr int E = elem_size<SRC>();
   constexpr int SUB = CSPM_ROW_SUB;
+  const double Gg = group_disp(pa, qxg_d, rowterm);  // the group's disparity base (device order, cspm_tap.h)
+  const double qxg = qxg_d;
+  qxg_d += (double)kRowMod;                          // exact: small integers
   const int adr_o = R.adr_o + g0 * 16, adr_g = R.adr_g + g0 * (SRC == kSrcCen ? 16 : 8), adr_p = R.adr_p + g0 * 4, off_g = R.lane_off + g0 * E;
-  tap_batch<SRC, VIEW, EDGE, STAGED, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel, e_span, qy,
+  tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy,
                                                                   cx_lane, S);
   if constexpr (CNT > SUB)
-    tap_batch<SRC, VIEW, EDGE, STAGED, SUB, (CNT < 2 * SUB ? CNT : 2 * SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel,
+    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, SUB, (CNT < 2 * SUB ? CNT : 2 * SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel,
                                                                               e_span, qy, cx_lane, S);
   if constexpr (CNT > 2 * SUB)
-    tap_batch<SRC, VIEW, EDGE, STAGED, 2 * SUB, CNT>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, rowterm, qx_d, e_rel, e_span, qy, cx_lane, S);
+    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 2 * SUB, CNT>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy, cx_lane, S);
 }
 
 // One window row of one level for all 64 lanes -> row total R (ROWTREE7: seven interleaved partial sums, combined left to right)
-template <int SRC, int VIEW, bool EDGE, bool STAGED>
+template <int SRC, int VIEW, bool EDGE, bool STAGED, bool ALLV = false>
 __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, const RowSrc &R, uint32_t Ip, double pa, double rowterm,
                                            double qx0_d, int e_lo, int e_span, int qy, int cx_lane) {
   double S[kRowMod];
@@ -319,10 +328,10 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
   const int full = A.n / kRowMod * kRowMod;
   int g0 = 0;
   for (; g0 < full; g0 += kRowMod)
-    tap_group<SRC, VIEW, EDGE, STAGED, kRowMod>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
+    tap_group<SRC, VIEW, EDGE, STAGED, ALLV, kRowMod>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
   // window sizes that are not a multiple of 7 (the usual 35 is): the remaining 1..6 taps
   switch (A.n - full) {
-#define CSPM_TAIL(K) case K: tap_group<SRC, VIEW, EDGE, STAGED, K>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S); break;
+#define CSPM_TAIL(K) case K: tap_group<SRC, VIEW, EDGE, STAGED, ALLV, K>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S); break;
     CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
 #undef CSPM_TAIL
     default: break;
@@ -335,6 +344,9 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
 
 // Per-wave description of the 64 evaluation centres of one pass (wave-uniform unless noted)
 struct RowCtx {
+#ifdef CSPM_ROW_STATS
+  int stat_slot;
+#endif
   int y;             // all lanes evaluate in row y
   int lane;
   char *strip;       // this wave's other-view strip, `cap` slots of 16 bytes
@@ -344,7 +356,11 @@ struct RowCtx {
 __device__ __forceinline__ RowCtx make_row_ctx(unsigned char *smem, int y, int cap, int ocap) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   char *base = reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * (size_t)(cap + ocap) * 16;
-  return RowCtx{y, (int)(threadIdx.x & 63), base, base + (size_t)cap * 16, cap, ocap};
+  return RowCtx{
+#ifdef CSPM_ROW_STATS
+      0,
+#endif
+      y, (int)(threadIdx.x & 63), base, base + (size_t)cap * 16, cap, ocap};
 }
 
 // One level of eval_rows for a wave: centres cx (per lane) in row cy (uniform), plane (a, b, c per lane) -> level sum.
@@ -444,9 +460,39 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
     }
     const double rowterm = b * (double)qy + c;  // q_disp_y, :155
     double Rsum;
-    if (staged) {
-      Rsum = edge ? row_taps<SRC, VIEW, true, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
-                  : row_taps<SRC, VIEW, false, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+#ifdef CSPM_ROW_STATS
+    {
+      const int jl = (A.n - 1) % kRowMod;
+      const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+      const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+      const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+      const bool safe = A.has_valid & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+      int f_lo = safe ? (int)fmin(q_first, q_last) : 0, f_hi = safe ? (int)fmax(q_first, q_last) + 1 : 0;
+      for (int off = 1; off < kWave; off <<= 1) {
+        f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
+        f_hi = max(f_hi, __shfl_xor(f_hi, off, kWave));
+      }
+      const int nd = f_hi - f_lo + 1;
+      int bucket = nd <= 4 ? 0 : nd <= 8 ? 1 : nd <= 16 ? 2 : nd <= 32 ? 3 : 4;
+      if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) bucket = 5;
+      if (!staged) bucket = 6;
+      if (lane == 0) atomicAdd(&g_rowstat[(ctx.stat_slot * 8 + s) * 8 + bucket], 1ull);
+    }
+#endif
+    if (staged && !edge) {
+      // The disparity along a window row is linear in the column (up to two roundings of < 2^-43 each while it is below 2^9): when
+      // it is inside [1 + 2^-20, D - 2^-20] at both end columns, every tap of the row has static_cast<int>(q_disp) in [1, D-1] --
+      // the interpolation branch of :166-175 -- and the taps need neither the clamp nor the test nor the select.  Decided per
+      // row for the whole wave (true for nearly every row once the planes have settled; random planes take the general path).
+      const int jl = (A.n - 1) % kRowMod;
+      const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+      const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+      const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+      const bool safe = A.has_valid & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+      Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? row_taps<SRC, VIEW, false, true, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
+                                                        : row_taps<SRC, VIEW, false, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+    } else if (staged) {
+      Rsum = row_taps<SRC, VIEW, true, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
     } else {
       Rsum = row_taps<SRC, VIEW, true, false>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
     }
@@ -464,6 +510,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
 #ifdef CSPM_COUNT_ALIVE
 __device__ unsigned long long g_alive[16];  // debug: lanes still alive after level s, lanes evaluated at level s
 #endif
+
 // A candidate plane as a lane holds it between uses: Plane::norm() and Plane::param()
 struct RowPlane {
   double nx, ny, nz, a, b, c;
@@ -597,7 +644,7 @@ __global__ __launch_bounds__(kRowBlock, CSPM_INIT_MINW) void k_init(Cost cd, Pm 
   RowItem it;
   if (!row_item(pm.W, pm.H, 2, it)) return;
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
+  RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;  // tail lanes shadow the last pixel
   auto gen = [&](int xs) { return init_plane(pm, it.v, xs, it.y); };
@@ -641,7 +688,7 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm
   RowItem it;
   if (!row_item(pm.W, pm.H, 2, it)) return;
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
+  RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;
   const long long i = (long long)it.y * pm.W + x;
@@ -649,6 +696,9 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm
   double cur_min = f.cost[i];
   const bool use_thresh = pm.use_thresh != 0 && *cd.early_ok != 0;
   for (int step = first_step; step < first_step + nsteps; ++step) {
+#ifdef CSPM_ROW_STATS
+    ctx.stat_slot = 2 + step;
+#endif
     auto gen = [&](int xs) { return refine_plane(pm, it.v, xs, it.y, iter, step, z_iter, n_iter); };
     const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, gen, cur_min, use_thresh);
     if (cost < cur_min) {                                                      // :335-338
@@ -706,7 +756,10 @@ __global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd
   RowItem it;
   if (!row_item(pm.W, pm.H, 1, it)) return;
   const int lane = threadIdx.x & 63;
-  const RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
+  RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
+#ifdef CSPM_ROW_STATS
+  ctx.stat_slot = 1;
+#endif
   const bool live = it.x0 + lane < pm.W;
   const int x = live ? it.x0 + lane : pm.W - 1;
   const int y = it.y;

@@ -15,6 +15,10 @@
 //   - level sum = balanced binary tree over R[0..63] (rows beyond the window and rows outside the image are +0.0;
 //     neighbours first).  An xor butterfly over 64 lanes computes it; so does one lane with six pending partial sums.
 //   Taps outside the image contribute nothing (the reference `continue`s; adding +0.0 is the same thing).
+// Contracted multiply-adds (one rounding instead of two; the oracle's CSOR_SUM_DEVICE order does the same):
+//   - the tap's disparity (group_disp / tap_disp below), the last step of a GRD cell (grd_cell), the interpolation between
+//     the two cells (lerp_cells) and the accumulation S[j] = fma(wgt, value, S[j]).  Everything else is compiled with
+//     -ffp-contract=off and rounds like the reference's SSE2 arithmetic.
 #pragma once
 #include "cspm_device.h"
 
@@ -64,7 +68,7 @@ constexpr unsigned kClrSat = 31;
 __device__ __forceinline__ double grd_cell(const double *lut_a, uint32_t Iq, double Gq, uint32_t Io, double Go) {
   const unsigned sad = min(__builtin_amdgcn_sad_u8(Iq, Io, 0u), kClrSat);
   const double grdDiff = __builtin_fmin(fabs(Gq - Go), 2.0);  // TAU_GRD
-  return lut_a[sad] + (1 - 0.1) * grdDiff;                    // ALPHA*clrDiff + (1-ALPHA)*grdDiff
+  return __builtin_fma(1 - 0.1, grdDiff, lut_a[sad]);         // ALPHA*clrDiff + (1-ALPHA)*grdDiff, contracted (device order)
 }
 // CenCC cell (cc/cen_cc.cc:54-62): Hamming distance of the two 80-bit codes, CENCUS_BIT = 80 when the other view's
 // pixel is outside the image (pad cells carry bit 31 in `pix`)
@@ -95,14 +99,13 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
 // The disparity of a tap split for the interpolation between two integer disparities (:166-175).
 //   valid  <=> static_cast<int>(q_disp) in [1, D-1]  <=> 1.0 <= q_disp < D        (else the "impossible disparity" branch)
 //   f      = that integer (clamped into [1, D-1] for invalid taps, so addresses stay inside the padded rows)
-//   fw     = floor_wgt = (f+1) - q_disp, ceil weight 1 - floor_wgt = q_disp - f
-// For a valid tap q_disp - f is the exact fraction (v_fract_f64), (f+1) - q_disp is exact too (Sterbenz: f >= 1), hence
-// floor_wgt == 1 - fract and 1 - floor_wgt == fract bit for bit: two instructions instead of five.
+//   fr     = 1 - floor_wgt = q_disp - f (the reference's ceil weight; floor_wgt = (f+1) - q_disp = 1 - fr)
+// For a valid tap q_disp - f is the exact fraction (v_fract_f64) and (f+1) - q_disp is exact too (Sterbenz: f >= 1).
 // NaN / out-of-range q_disp saturate in v_cvt_i32_f64 (NaN -> 0) and fail `clamped == raw`, as x86 cvttsd2si's INT_MIN does.
 struct DispSplit {
   bool valid;
   int f;
-  double fw, fr;
+  double fr;
 };
 __device__ __forceinline__ DispSplit split_disp(double q_disp, int Dm1, bool level_has_valid) {
   DispSplit s;
@@ -110,15 +113,28 @@ __device__ __forceinline__ DispSplit split_disp(double q_disp, int Dm1, bool lev
   s.f = med3_i32(f0, 1, Dm1);
   s.valid = (s.f == f0) & level_has_valid;  // level_has_valid: D >= 2 (otherwise [1, D-1] is empty)
   s.fr = __builtin_amdgcn_fract(q_disp);
-  s.fw = 1.0 - s.fr;
   return s;
 }
-// interpolated cost of the tap, weighted (:173-176)
-__device__ __forceinline__ double tap_value(const DispSplit &s, double c0, double c1, double maxc, double wgt) {
-  double tmp = s.fw * c0 + s.fr * c1;
-  tmp = s.valid ? tmp : maxc;  // :169
-  return wgt * tmp;            // :176
+// the same for a tap whose q_disp is known to lie in [1, D): no clamp, no test
+__device__ __forceinline__ DispSplit split_disp_valid(double q_disp) {
+  DispSplit s;
+  s.f = cvt_i32_sat(q_disp);
+  s.valid = true;
+  s.fr = __builtin_amdgcn_fract(q_disp);
+  return s;
 }
+// interpolated cost of the tap (:173-175; the "impossible disparity" branch :166-169).  Device order: floor_wgt*c0 +
+// (1-floor_wgt)*c1 is formed as c0 + fr*(c1-c0) with ONE fma (floor_wgt = 1-fr and 1-floor_wgt = fr exactly for a valid tap).
+__device__ __forceinline__ double lerp_cells(double fr, double c0, double c1) { return __builtin_fma(fr, c1 - c0, c0); }
+__device__ __forceinline__ double tap_value(const DispSplit &s, double c0, double c1, double maxc) {
+  const double tmp = lerp_cells(s.fr, c0, c1);
+  return s.valid ? tmp : maxc;
+}
+// A tap's disparity in the device order: formed per group of kRowMod window columns -- q_disp(dx) = fma(a, dx % 7, G) with
+// G = fma(a, q_x of the group's first column, q_disp_y)   (the reference: a*q_x + q_disp_y, pre_cs_pc.cc:155,165).  Both
+// engines get the multiplier dx % 7 for free (row engine: a compile-time constant; chain engine: a lane constant).
+__device__ __forceinline__ double group_disp(double a, double qx_group, double q_disp_y) { return __builtin_fma(a, qx_group, q_disp_y); }
+__device__ __forceinline__ double tap_disp(double a, double j, double G) { return __builtin_fma(a, j, G); }
 
 // ---- GrdPC / CSPC tap (plane_cost/grd_pc.cc:125-169 without USE_INTER, cspc.cc:145-174) ----
 //   valid  <=> static_cast<int>(q_disp) in [1, D-1], as above

@@ -252,6 +252,18 @@ static inline double cost_grd_border(const double *lC, const double *lG) {
   return ALPHA * clrDiff + (1 - ALPHA) * grdDiff;
 }
 
+/* The same cell in the DEVICE order: identical terms, the final multiply-add contracted into one
+ * fma -- one rounding fewer than grd_cc.cpp:18.  Only CSOR_SUM_DEVICE evaluations read these cells. */
+static inline double cost_grd_dev(const double *lC, const double *rC, double lG, double rG) {
+  double clrDiff = 0;
+  for (int c = 0; c < 3; c++) clrDiff += fabs(lC[c] - rC[c]);
+  clrDiff *= 0.3333333333;
+  double grdDiff = fabs(lG - rG);
+  clrDiff = clrDiff > TAU_CLR ? TAU_CLR : clrDiff;
+  grdDiff = grdDiff > TAU_GRD ? TAU_GRD : grdDiff;
+  return fma(1 - ALPHA, grdDiff, ALPHA * clrDiff);
+}
+
 static void grd_prepare(const double *l, const double *r, int w, int h, double **lG, double **rG) {
   float *g = (float *)malloc(sizeof(float) * (size_t)w * h);
   *lG = (double *)malloc(sizeof(double) * (size_t)w * h);
@@ -293,6 +305,30 @@ void csor_grd_build_right_cv(const double *l, const double *r, int w, int h, int
       for (int x = 0; x < w; x++) {
         if (x + d < w) cost[x] = cost_grd(lData + 3 * (x + d), rData + 3 * x, lGData + x + d, rGData + x);
         else cost[x] = cost_grd_border(rData + 3 * x, rGData + x);
+      }
+    }
+  free(lG);
+  free(rG);
+}
+
+/* both views' GRD volumes in the device order (cost_grd_dev); border cells as grd_cc.cpp:88-100,134-147 */
+static void grd_build_dev(const double *l, const double *r, int w, int h, int maxDis, int right, double *vol) {
+  double *lG, *rG;
+  grd_prepare(l, r, w, h, &lG, &rG);
+  const double bc[3] = {BORDER_THRES, BORDER_THRES, BORDER_THRES};
+  for (int d = 0; d < maxDis; d++)
+    for (int y = 0; y < h; y++) {
+      const double *lData = l + (size_t)y * w * 3, *rData = r + (size_t)y * w * 3;
+      const double *lGData = lG + (size_t)y * w, *rGData = rG + (size_t)y * w;
+      double *cost = vol + ((size_t)d * h + y) * w;
+      for (int x = 0; x < w; x++) {
+        if (!right) {
+          if (x - d >= 0) cost[x] = cost_grd_dev(lData + 3 * x, rData + 3 * (x - d), lGData[x], rGData[x - d]);
+          else cost[x] = cost_grd_dev(lData + 3 * x, bc, lGData[x], BORDER_THRES);
+        } else {
+          if (x + d < w) cost[x] = cost_grd_dev(lData + 3 * (x + d), rData + 3 * x, lGData[x + d], rGData[x]);
+          else cost[x] = cost_grd_dev(rData + 3 * x, bc, rGData[x], BORDER_THRES);
+        }
       }
     }
   free(lG);
@@ -380,6 +416,11 @@ struct csor_pc {
   int img_kind;  /* 1: GrdPC / CSPC -- no volumes, cells computed from the images at real-valued positions */
   double *grd[2][CSOR_MAX_LEVELS]; /* GrdPC::grd_x_ / CSPC::grd_x_ (img_kind only) */
   double max_cost[2][CSOR_MAX_LEVELS];
+  /* CSOR_SUM_DEVICE ("device order"): GRD cells with the last step contracted,
+   * fma(1-ALPHA, grdDiff, ALPHA*clrDiff), and their max.  NULL / equal to the above when the device reads the very same
+   * cells (census: exact integers; volumes a test overwrote = a foreign CCMethod). */
+  double *vol_dev[2][CSOR_MAX_LEVELS];
+  double max_cost_dev[2][CSOR_MAX_LEVELS];
   double scale_wgt[CSOR_MAX_LEVELS];
   double lookup_exp[1000];
 };
@@ -422,15 +463,21 @@ static inline int handle_border(int loc, int size) {
   return loc;
 }
 
-void csor_pc_refresh_max_cost(csor_pc *pc) { /* pre_cs_pc.cc:75-82, pre_ss_pc.cc:51-58 */
+static double vol_max(const csor_pc *pc, const double *vol, int s) { /* pre_cs_pc.cc:75-82, pre_ss_pc.cc:51-58 */
+  double m = -1.0;
+  const size_t n = (size_t)(pc->max_disp[s] + 1) * pc->hei[s] * pc->wid[s];
+  for (size_t i = 0; i < n; ++i)
+    if (vol[i] > m) m = vol[i];
+  return m;
+}
+/* The caller replaced the volumes (a foreign CCMethod's cells): both summation orders read exactly these cells. */
+void csor_pc_refresh_max_cost(csor_pc *pc) {
   if (pc->img_kind) return;
   for (int v = 0; v < 2; ++v)
     for (int s = 0; s < pc->scale_num; ++s) {
-      double m = -1.0;
-      const size_t n = (size_t)(pc->max_disp[s] + 1) * pc->hei[s] * pc->wid[s];
-      for (size_t i = 0; i < n; ++i)
-        if (pc->vol[v][s][i] > m) m = pc->vol[v][s][i];
-      pc->max_cost[v][s] = m;
+      free(pc->vol_dev[v][s]);
+      pc->vol_dev[v][s] = NULL;
+      pc->max_cost[v][s] = pc->max_cost_dev[v][s] = vol_max(pc, pc->vol[v][s], s);
     }
 }
 
@@ -475,7 +522,7 @@ csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, in
         pc->grd[v][s] = (double *)malloc(sizeof(double) * (size_t)W * H);
         sobel_x_ks1_u8(gray, W, H, pc->grd[v][s]);
         free(gray);
-        pc->max_cost[v][s] = IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD;
+        pc->max_cost[v][s] = pc->max_cost_dev[v][s] = IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD;
       }
     if (pc->cs) csor_scale_weights(pc->scale_num, reg_lambda, pc->scale_wgt); /* cspc.cc:63-87 */
     else pc->scale_wgt[0] = 1.0;
@@ -495,11 +542,19 @@ csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, in
     } else {
       csor_grd_build_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[0][s]);
       csor_grd_build_right_cv(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, pc->vol[1][s]);
+      for (int v = 0; v < 2; ++v) {
+        pc->vol_dev[v][s] = (double *)calloc(n, sizeof(double));
+        grd_build_dev(tl, tr, pc->wid[s], pc->hei[s], pc->max_disp[s] + 1, v, pc->vol_dev[v][s]);
+      }
     }
     free(tl);
     free(tr);
   }
-  csor_pc_refresh_max_cost(pc);
+  for (int v = 0; v < 2; ++v)
+    for (int s = 0; s < pc->scale_num; ++s) {
+      pc->max_cost[v][s] = vol_max(pc, pc->vol[v][s], s);
+      pc->max_cost_dev[v][s] = pc->vol_dev[v][s] ? vol_max(pc, pc->vol_dev[v][s], s) : pc->max_cost[v][s];
+    }
   if (pc->cs) csor_scale_weights(pc->scale_num, reg_lambda, pc->scale_wgt);
   else pc->scale_wgt[0] = 1.0;
   csor_exp_lut(pc->lookup_exp, WGT_GAMMA);
@@ -509,7 +564,7 @@ csor_pc *csor_pc_create_cc(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, in
 void csor_pc_destroy(csor_pc *pc) {
   if (!pc) return;
   for (int v = 0; v < 2; ++v)
-    for (int s = 0; s < pc->scale_num; ++s) { free(pc->img[v][s]); free(pc->vol[v][s]); free(pc->grd[v][s]); }
+    for (int s = 0; s < pc->scale_num; ++s) { free(pc->img[v][s]); free(pc->vol[v][s]); free(pc->vol_dev[v][s]); free(pc->grd[v][s]); }
   free(pc);
 }
 int csor_pc_levels(const csor_pc *pc) { return pc->scale_num; }
@@ -517,6 +572,9 @@ void csor_pc_level_dims(const csor_pc *pc, int s, int *w, int *h, int *md) { *w 
 const uint8_t *csor_pc_image(const csor_pc *pc, int view, int s) { return pc->img[view][s]; }
 double *csor_pc_volume(csor_pc *pc, int view, int s) { return pc->vol[view][s]; }
 double csor_pc_max_cost(const csor_pc *pc, int view, int s) { return pc->max_cost[view][s]; }
+/* the cells / max_cost a CSOR_SUM_DEVICE evaluation reads */
+double *csor_pc_volume_dev(csor_pc *pc, int view, int s) { return pc->vol_dev[view][s] ? pc->vol_dev[view][s] : pc->vol[view][s]; }
+double csor_pc_max_cost_dev(const csor_pc *pc, int view, int s) { return pc->max_cost_dev[view][s]; }
 const double *csor_pc_scale_wgt(const csor_pc *pc) { return pc->scale_wgt; }
 
 /* static_cast<int>(double) as x86 cvttsd2si executes it: out-of-range / NaN -> INT_MIN, which
@@ -526,18 +584,20 @@ static inline int trunc_x86(double q) {
   return (int)q;
 }
 
-/* one window tap: pre_cs_pc.cc:160-177 / pre_ss_pc.cc:94-110.  returns wgt * interpolated cost */
+/* one window tap: pre_cs_pc.cc:160-177 / pre_ss_pc.cc:94-110.  Returns the guide weight in *wgt_out and the (interpolated)
+ * cost it multiplies; q_disp is the caller's (the two summation orders form it differently, see level_cost).
+ * dev != 0: the device order's cells and its contracted interpolation c0 + fr*(c1 - c0) as ONE fma -- the same value as
+ * floor_wgt*c0 + (1-floor_wgt)*c1 up to rounding (floor_wgt = 1 - fr and 1 - floor_wgt = fr exactly for a valid tap). */
 static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p, int q_x, int q_y,
-                         double plane_a, double q_disp_y) {
+                         double q_disp, int dev, double *wgt_out) {
   const uint8_t *I_q = pc->img[view][s] + ((size_t)q_y * pc->wid[s] + q_x) * 3;
   int sum = abs(I_p[0] - I_q[0]) + abs(I_p[1] - I_q[1]) + abs(I_p[2] - I_q[2]);
-  const double wgt = pc->lookup_exp[sum];
-  double q_disp = plane_a * q_x + q_disp_y;
+  *wgt_out = pc->lookup_exp[sum];
   int q_disp_floor = trunc_x86(q_disp);
   if (pc->img_kind) {
     /* GrdPC::GetPlaneCost (grd_pc.cc:128-169, the !USE_INTER build) / CSPC::GetPlaneCost (cspc.cc:147-174) */
     if (q_disp_floor <= 0 || q_disp_floor >= pc->max_disp[s])
-      return wgt * (IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD);
+      return IMG_COST_ALPHA * IMG_TAU_CLR + (1 - IMG_COST_ALPHA) * IMG_TAU_GRD;
     const int W = pc->wid[s];
     const double other_x = q_x + (2 * view - 1) * q_disp;
     int floor_x = trunc_x86(other_x);
@@ -555,16 +615,21 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
     const double G_floor = G_other_y[floor_x], G_ceil = G_other_y[ceil_x];
     const double G_q = pc->grd[view][s][(size_t)q_y * W + q_x];
     const double grd_cost = fabs(G_q - G_ceil + floor_wgt * (G_ceil - G_floor));
-    return wgt * (IMG_COST_ALPHA * (clr_cost < IMG_TAU_CLR ? clr_cost : IMG_TAU_CLR) +
-                  (1 - IMG_COST_ALPHA) * (grd_cost < IMG_TAU_GRD ? grd_cost : IMG_TAU_GRD));
+    return IMG_COST_ALPHA * (clr_cost < IMG_TAU_CLR ? clr_cost : IMG_TAU_CLR) +
+           (1 - IMG_COST_ALPHA) * (grd_cost < IMG_TAU_GRD ? grd_cost : IMG_TAU_GRD);
   }
-  if (q_disp_floor <= 0 || q_disp_floor >= pc->max_disp[s]) return wgt * pc->max_cost[view][s];
+  if (q_disp_floor <= 0 || q_disp_floor >= pc->max_disp[s]) return dev ? pc->max_cost_dev[view][s] : pc->max_cost[view][s];
+  const size_t slab = (size_t)pc->hei[s] * pc->wid[s];
+  const size_t at = (size_t)q_disp_floor * slab + (size_t)q_y * pc->wid[s] + q_x;
+  if (dev) {
+    const double *c0 = (pc->vol_dev[view][s] ? pc->vol_dev[view][s] : pc->vol[view][s]) + at;
+    const double fr = q_disp - (double)q_disp_floor; /* exact */
+    return fma(fr, c0[slab] - c0[0], c0[0]);
+  }
   int q_disp_ceil = q_disp_floor + 1;
   const double floor_wgt = q_disp_ceil - q_disp;
-  const size_t slab = (size_t)pc->hei[s] * pc->wid[s];
-  const double *c0 = pc->vol[view][s] + (size_t)q_disp_floor * slab + (size_t)q_y * pc->wid[s] + q_x;
-  double tmp = floor_wgt * c0[0] + (1 - floor_wgt) * c0[slab];
-  return wgt * tmp;
+  const double *c0 = pc->vol[view][s] + at;
+  return floor_wgt * c0[0] + (1 - floor_wgt) * c0[slab];
 }
 
 #define ROWMOD_K 7   /* CSOR_SUM_DEVICE: interleaved partial sums per window row */
@@ -575,8 +640,11 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
  * base + partial*mul >= thresh (meaningful only when every term is >= 0; serial order: after every window row,
  * device order: at the level end).  Returns 1 and the level sum in *sum, or 0 if rejected early.
  *
- * CSOR_SUM_SERIAL: one running sum over (dy outer, dx inner) -- the reference's order.
- * CSOR_SUM_DEVICE ("ROWTREE7"):
+ * CSOR_SUM_SERIAL: one running sum over (dy outer, dx inner) -- the reference's order and arithmetic.
+ * CSOR_SUM_DEVICE ("ROWTREE7" with contracted multiply-adds):
+ *   - a tap's disparity is formed per group of 7 window columns: q_disp(dx) = fma(a, dx % 7, G) with
+ *     G = fma(a, q_x of the group's first column, q_disp_y)  (the reference: a*q_x + q_disp_y, pre_cs_pc.cc:165);
+ *   - cells and interpolation as tap(dev = 1); a tap enters its partial sum as S = fma(wgt, value, S);
  *   - within window row dy (0-based), tap dx (0-based window column) is accumulated in dx order into the partial sum
  *     S[dx % 7]; the row total is R[dy] = (((((S0+S1)+S2)+S3)+S4)+S5)+S6;
  *   - the level sum is the balanced binary tree over R[0..63] (rows >= the window size and rows outside the image are
@@ -599,7 +667,12 @@ static int level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double
     if (sum_order == CSOR_SUM_SERIAL) {
       for (int dx = -half; dx <= half; ++dx) {
         int q_x = cx + dx;
-        if (q_x >= 0 && q_x < W) { acc += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y); ++nt; }
+        if (q_x >= 0 && q_x < W) {
+          double wgt;
+          const double t = tap(pc, view, s, I_p, q_x, q_y, a * q_x + q_disp_y, 0, &wgt); /* :165 */
+          acc += wgt * t; /* :176-177 */
+          ++nt;
+        }
       }
       if (use_thresh && base + acc * mul >= thresh) { if (taps) *taps += nt; return 0; }
     } else {
@@ -607,7 +680,14 @@ static int level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double
       for (int j = 0; j < ROWMOD_K; ++j) S[j] = 0.0;
       for (int dx = -half; dx <= half; ++dx) {
         int q_x = cx + dx;
-        if (q_x >= 0 && q_x < W) { S[(dx + half) % ROWMOD_K] += tap(pc, view, s, I_p, q_x, q_y, a, q_disp_y); ++nt; }
+        const int col = dx + half, j = col % ROWMOD_K;
+        if (q_x >= 0 && q_x < W) {
+          const double G = fma(a, (double)(q_x - j), q_disp_y);
+          double wgt;
+          const double t = tap(pc, view, s, I_p, q_x, q_y, fma(a, (double)j, G), 1, &wgt);
+          S[j] = fma(wgt, t, S[j]);
+          ++nt;
+        }
       }
       double r = S[0];
       for (int j = 1; j < ROWMOD_K; ++j) r = r + S[j];

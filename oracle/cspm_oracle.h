@@ -32,7 +32,9 @@ enum { CSOR_LEFT = 0, CSOR_RIGHT = 1 };           /* commfunc.h:29  enum RefView
 enum {
   CSOR_SUM_SERIAL = 0,  /* reference order: dy outer, dx inner, one accumulator (pre_cs_pc.cc:151-181) */
   CSOR_SUM_DEVICE = 1   /* device order "ROWTREE7": per window row, tap dx goes to partial sum S[dx % 7] in dx order; row total
-                           = ((((((S0+S1)+S2)+S3)+S4)+S5)+S6); level sum = balanced binary tree over the 64 (zero-padded) row totals */
+                           = ((((((S0+S1)+S2)+S3)+S4)+S5)+S6); level sum = balanced binary tree over the 64 (zero-padded) row totals.
+                           Multiply-adds are contracted (fma) at the sites DESIGN.md section 3.2 lists: the tap's disparity, the
+                           last step of a GRD cell, the interpolation between the two cells, the accumulation */
 };
 
 /* propagation schedule of SpatialPropagation */
@@ -94,6 +96,10 @@ void     csor_pc_level_dims(const csor_pc *pc, int s, int *w, int *h, int *max_d
 const uint8_t *csor_pc_image(const csor_pc *pc, int view, int s);     /* packed BGR of level s */
 double  *csor_pc_volume(csor_pc *pc, int view, int s);                /* (max_disp_s+1) slabs */
 double   csor_pc_max_cost(const csor_pc *pc, int view, int s);
+/* what a CSOR_SUM_DEVICE evaluation reads: GRD cells with the contracted last step and their max; the plain volumes
+ * for census and after csor_pc_refresh_max_cost (a foreign CCMethod's cells are taken as they are) */
+double  *csor_pc_volume_dev(csor_pc *pc, int view, int s);
+double   csor_pc_max_cost_dev(const csor_pc *pc, int view, int s);
 void     csor_pc_refresh_max_cost(csor_pc *pc);   /* after a test overwrote volumes (foreign CCMethod) */
 const double *csor_pc_scale_wgt(const csor_pc *pc);
 /* IPlaneCost::GetPlaneCost (i_plane_cost.h:28-33).  norm/point/param as in class Plane. */

@@ -65,6 +65,8 @@ def lib():
         "csor_pc_image": (u8p, [C.c_void_p, C.c_int, C.c_int]),
         "csor_pc_volume": (dp, [C.c_void_p, C.c_int, C.c_int]),
         "csor_pc_max_cost": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+        "csor_pc_volume_dev": (dp, [C.c_void_p, C.c_int, C.c_int]),
+        "csor_pc_max_cost_dev": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
         "csor_pc_refresh_max_cost": (None, [C.c_void_p]),
         "csor_pc_scale_wgt": (dp, [C.c_void_p]),
         "csor_pc_cost": (C.c_double, [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int]),
@@ -141,6 +143,14 @@ class PlaneCost:
 
     def max_cost(self, view, s):
         return self.L.csor_pc_max_cost(self.p, view, s)
+
+    def volume_dev(self, view, s):
+        """the cells a SUM_DEVICE evaluation reads: GRD cells with the contracted last step; otherwise volume()"""
+        w, h, d = self.dims(s)
+        return np.ctypeslib.as_array(self.L.csor_pc_volume_dev(self.p, view, s), shape=(d + 1, h, w))
+
+    def max_cost_dev(self, view, s):
+        return self.L.csor_pc_max_cost_dev(self.p, view, s)
 
     def refresh_max_cost(self):
         self.L.csor_pc_refresh_max_cost(self.p)

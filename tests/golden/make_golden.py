@@ -40,6 +40,10 @@ def cost_fixture():
         out[f"{name}_vol_sha"] = np.array([[sha(pc.volume(v, s)) for s in range(pc.levels)] for v in (0, 1)])
         out[f"{name}_img_sha"] = np.array([[sha(pc.image(v, s)) for s in range(pc.levels)] for v in (0, 1)])
         out[f"{name}_vol0_d5"] = np.stack([pc.volume(v, 0)[5].copy() for v in (0, 1)])
+        # the cells / max_cost of the device order (GRD cells with the contracted last step)
+        out[f"{name}_maxc_dev"] = np.array([[pc.max_cost_dev(v, s) for s in range(pc.levels)] for v in (0, 1)])
+        out[f"{name}_vol_dev_sha"] = np.array([[sha(pc.volume_dev(v, s)) for s in range(pc.levels)] for v in (0, 1)])
+        out[f"{name}_vol0_d5_dev"] = np.stack([pc.volume_dev(v, 0)[5].copy() for v in (0, 1)])
         rng = np.random.default_rng(2024)
         n = 1000
         for v in (0, 1):

@@ -4,6 +4,7 @@ It exists to catch restatement mistakes in the C oracle: two independent reading
 bit for bit.  (Random draws are taken from the oracle's counter-based generator: the reference's
 cv::RNG(time(NULL)) stream is not reproducible.)"""
 import math
+from fractions import Fraction
 
 import numpy as np
 
@@ -50,7 +51,18 @@ def gray_grad(bgr):  # grd_cc.cpp:70-77 on the RGB-converted CV_64F image
     return G
 
 
-def grd_volume(l_bgr, r_bgr, max_dis_slabs, right):  # grd_cc.cpp:60-154 + myCostGrd :4-35
+def fma(a, b, c):
+    """a*b + c with ONE rounding, computed exactly in rational arithmetic (no libm, no hardware fma)."""
+    a, b, c = float(a), float(b), float(c)
+    if not (math.isfinite(a) and math.isfinite(b) and math.isfinite(c)):
+        return a * b + c
+    r = Fraction(a) * Fraction(b) + Fraction(c)
+    if r == 0:
+        return a * b + c  # keeps the sign of zero of the unfused expression (equal for +0.0 accumulators)
+    return float(r)  # int / int true division: correctly rounded
+
+
+def grd_volume(l_bgr, r_bgr, max_dis_slabs, right, dev=False):  # grd_cc.cpp:60-154 + myCostGrd :4-35
     L = l_bgr[..., ::-1].astype(np.float64)  # RGB
     R = r_bgr[..., ::-1].astype(np.float64)
     lG, rG = gray_grad(l_bgr), gray_grad(r_bgr)
@@ -77,7 +89,10 @@ def grd_volume(l_bgr, r_bgr, max_dis_slabs, right):  # grd_cc.cpp:60-154 + myCos
             grd = np.abs(own_g - oth_g)
             clr = np.where(clr > 10.0, 10.0, clr)
             grd = np.where(grd > 2.0, 2.0, grd)
-            vol[d, :, x] = 0.1 * clr + (1 - 0.1) * grd
+            if dev:  # the device order's cell: the last multiply-add is one fma
+                vol[d, :, x] = [fma(1 - 0.1, g, 0.1 * c) for c, g in zip(clr, grd)]
+            else:
+                vol[d, :, x] = 0.1 * clr + (1 - 0.1) * grd
     return vol
 
 
@@ -133,7 +148,7 @@ def plane_param(n, p):  # plane.h:25-34
 class PlaneCost:
     """PreSSPC (scale_num=0) / PreCSPC: pre_ss_pc.cc, pre_cs_pc.cc"""
 
-    def __init__(self, l, r, max_disp, wnd, scale_num, lam, cc="GRD"):
+    def __init__(self, l, r, max_disp, wnd, scale_num, lam, cc="GRD", dev=True):
         build = cen_volume if cc == "CEN" else grd_volume
         self.cs = scale_num > 0
         S = scale_num if self.cs else 1
@@ -151,9 +166,16 @@ class PlaneCost:
             self.grd = [[img_grad(self.img[v][s]) for s in range(S)] for v in (0, 1)]
             self.vol = [[None] * S, [None] * S]
             self.max_cost = [[0.1 * 10.0 + (1 - 0.1) * 2.0] * S for v in (0, 1)]  # grd_pc.cc:131-132, cspc.cc:150-152
+            self.vol_dev, self.max_cost_dev = self.vol, self.max_cost
         else:
             self.vol = [[build(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1) for s in range(S)] for v in (0, 1)]
             self.max_cost = [[max(-1.0, float(self.vol[v][s].max())) for s in range(S)] for v in (0, 1)]
+            # what the device order reads: GRD cells with the contracted last step; census cells are integers
+            self.vol_dev, self.max_cost_dev = self.vol, self.max_cost
+            if cc == "GRD" and dev:
+                self.vol_dev = [[grd_volume(self.img[0][s], self.img[1][s], self.dims[s][2] + 1, v == 1, dev=True) for s in range(S)]
+                                for v in (0, 1)]
+                self.max_cost_dev = [[max(-1.0, float(self.vol_dev[v][s].max())) for s in range(S)] for v in (0, 1)]
         if self.cs:
             M = np.zeros((S, S))
             for s in range(S):
@@ -177,7 +199,8 @@ class PlaneCost:
         row K interleaved partial sums (window column % K) combined left to right; the row totals (zero-padded to 64) are
         combined by a balanced binary tree (neighbours first)."""
         w, h, D = self.dims[s]
-        img, vol, maxc = self.img[v][s].astype(np.int64), self.vol[v][s], self.max_cost[v][s]
+        img = self.img[v][s].astype(np.int64)
+        vol, maxc = (self.vol_dev[v][s], self.max_cost_dev[v][s]) if rowmod else (self.vol[v][s], self.max_cost[v][s])
         cost = 0.0
         rows = [0.0] * 64
         Ip = img[cy, cx]
@@ -192,19 +215,27 @@ class PlaneCost:
                 if qx < 0 or qx >= w:
                     continue
                 wgt = self.lut[int(np.abs(Ip - img[qy, qx]).sum())]
-                qd = a * qx + qdy
+                if rowmod:
+                    # device order: the disparity is formed per group of `rowmod` window columns, two fused multiply-adds
+                    j = (dx + self.half) % rowmod
+                    qd = fma(a, float(j), fma(a, float(qx - j), qdy))
+                else:
+                    qd = a * qx + qdy
                 f = int(qd) if (qd == qd and abs(qd) < 2 ** 31) else -(2 ** 31)  # cvttsd2si
                 if f <= 0 or f >= D:
-                    term = wgt * maxc
+                    val = maxc
                 elif self.img_kind:
-                    term = wgt * self._img_cell(v, s, qx, qy, qd)
+                    val = self._img_cell(v, s, qx, qy, qd)
+                elif rowmod:
+                    c0, c1 = vol[f, qy, qx], vol[f + 1, qy, qx]
+                    val = fma(qd - f, c1 - c0, c0)  # c0 + fr*(c1 - c0), one rounding
                 else:
                     fw = (f + 1) - qd
-                    term = wgt * (fw * vol[f, qy, qx] + (1 - fw) * vol[f + 1, qy, qx])
+                    val = fw * vol[f, qy, qx] + (1 - fw) * vol[f + 1, qy, qx]
                 if rowmod:
-                    part[(dx + self.half) % rowmod] += term
+                    part[(dx + self.half) % rowmod] = fma(wgt, val, part[(dx + self.half) % rowmod])
                 else:
-                    cost += term
+                    cost += wgt * val
             if rowmod:
                 row = part[0]
                 for j in range(1, rowmod):

@@ -30,8 +30,9 @@ def test_pyramid_volumes_bit_exact(gpu_ctx, request, pairname, name, scale_num, 
         assert gpu_ctx.level_dims(s) == pc.dims(s)
         for v in (0, 1):
             np.testing.assert_array_equal(gpu_ctx.level_image(v, s), pc.image(v, s))
-            np.testing.assert_array_equal(gpu_ctx.cost_volume(v, s), pc.volume(v, s))
-            assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
+            # the cells the plane cost reads on the device: GRD cells of the device order (last multiply-add contracted)
+            np.testing.assert_array_equal(gpu_ctx.cost_volume(v, s), pc.volume_dev(v, s))
+            assert gpu_ctx.max_cost(v, s) == pc.max_cost_dev(v, s)
 
 
 def test_grd_build_cv_host_boundary(small_pair):
@@ -196,9 +197,9 @@ def test_golden_cost_fixture(gpu_ctx):
         gpu_ctx.build_cost_grd(int(g["max_dis"]), 35, sn, lam)
         np.testing.assert_array_equal(gpu_ctx.scale_weights(), g[f"{name}_wgt"])
         for v in (0, 1):
-            np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 5), g[f"{name}_vol0_d5"][v])
+            np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 5), g[f"{name}_vol0_d5_dev"][v])
             for s in range(gpu_ctx.levels):
-                assert gpu_ctx.max_cost(v, s) == g[f"{name}_maxc"][v, s]
+                assert gpu_ctx.max_cost(v, s) == g[f"{name}_maxc_dev"][v, s]
             got = gpu_ctx.plane_cost_batch(v, g[f"{name}_v{v}_xy"], g[f"{name}_v{v}_np"])
             np.testing.assert_array_equal(got, g[f"{name}_v{v}_device"])
             np.testing.assert_allclose(got, g[f"{name}_v{v}_serial"], rtol=1e-12, atol=0)

@@ -28,9 +28,9 @@ def test_c3_sampled_plane_costs_equal_the_oracle(gpu_ctx, c3):
     rng = np.random.default_rng(17)
     for v in (0, 1):
         for s in range(5):
-            assert gpu_ctx.max_cost(v, s) == pc.max_cost(v, s)
-        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 77), pc.volume(v, 0)[77])
-        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 2, 32), pc.volume(v, 2)[32])
+            assert gpu_ctx.max_cost(v, s) == pc.max_cost_dev(v, s)
+        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 0, 77), pc.volume_dev(v, 0)[77])
+        np.testing.assert_array_equal(gpu_ctx.cost_slab(v, 2, 32), pc.volume_dev(v, 2)[32])
         xy, norm, point, param = random_planes(rng, 400, cfg["w"], cfg["h"], cfg["max_dis"])
         got = gpu_ctx.plane_cost_batch(v, xy, np.concatenate([norm, param], 1))
         want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], v, po.SUM_DEVICE) for i in range(len(xy))])

@@ -64,6 +64,11 @@ def test_volumes_and_max_cost(scale_num, lam):
             np.testing.assert_array_equal(pc.image(v, s), ref.img[v][s])
             np.testing.assert_array_equal(pc.volume(v, s), ref.vol[v][s])
             assert pc.max_cost(v, s) == ref.max_cost[v][s]
+            # the device order's cells (last multiply-add contracted; pyref: exact rational fma): rounding-level difference only
+            np.testing.assert_array_equal(pc.volume_dev(v, s), ref.vol_dev[v][s])
+            assert pc.max_cost_dev(v, s) == ref.max_cost_dev[v][s]
+            np.testing.assert_allclose(pc.volume_dev(v, s), pc.volume(v, s), rtol=4e-16, atol=0)
+            assert np.any(pc.volume_dev(v, s) != pc.volume(v, s))
     # GRD cost is bounded by ALPHA*TAU_CLR + (1-ALPHA)*TAU_GRD = 2.8 and non-negative
     assert 0.0 <= pc.volume(0, 0).min() and pc.volume(0, 0).max() <= 0.1 * 10.0 + (1 - 0.1) * 2.0
     # border branch: left view, x < d uses the constant-3 "other" pixel
