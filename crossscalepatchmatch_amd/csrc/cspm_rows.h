@@ -193,6 +193,7 @@ struct RowSrc {
   // staged: LDS addresses (lds_addr) of window column 0 of the lane: other strip at f = 0 (biased one slot down for the left
   // view, see rd_cells); own strip gradient / colour arrays
   int adr_o, adr_g, adr_p;
+  int adr_g2, adr_g3;  // == adr_g, but opaque to the compiler (see tap_batch stage 1)
   // unstaged: image rows in global memory and the byte offset of the lane's window column 0
   const char *own_row, *oth_row;
   int lane_off;
@@ -213,7 +214,7 @@ struct RowSrc {
 //   ALLV   : every tap of this window row is known to take the interpolation branch in every lane (level_rows decides that per
 //            row from the two end columns): no clamp, no validity test, no select -- 4 instructions per tap less
 template <int SRC, int VIEW, bool EDGE, bool STAGED, bool ALLV, int J0, int J1>
-__device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, int adr_o, int adr_g, int adr_p, int off_g,
+__device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, int adr_o, int adr_g, int adr_g2, int adr_g3, int adr_p, int off_g,
                                           uint32_t Ip, double pa, double Gg, double qxg_d, int e_rel, int e_span, int qy, int cx_lane,
                                           double S[kRowMod]) {
   constexpr int E = elem_size<SRC>();
@@ -226,9 +227,10 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
   uint4 P[N], o0[N], o1[N];
   double fr[N], wgt[N], tmp[N];
   bool valid[N], in_img[N];
-  // stage 1: own elements
+  // stage 1: own elements.  (The taps of a batch address the gradient array through separate, laundered copies of its base: two
+  // 8-byte reads off the same register would be merged into one ds_read2_b64, which runs at half the rate of ds_read_b64.)
 #pragma unroll
-  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(adr_g, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
+  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(k == 0 ? adr_g : k == 1 ? adr_g2 : adr_g3, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
   // stage 2: disparities (pure arithmetic), then the cells of the other view
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -308,13 +310,14 @@ __device__ __forceinline__ void tap_group(const RowLevel &A, const Luts &lut, co
   const double qxg = qxg_d;
   qxg_d += (double)kRowMod;                          // exact: small integers
   const int adr_o = R.adr_o + g0 * 16, adr_g = R.adr_g + g0 * (SRC == kSrcCen ? 16 : 8), adr_p = R.adr_p + g0 * 4, off_g = R.lane_off + g0 * E;
-  tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy,
+  const int adr_g2 = R.adr_g2 + g0 * (SRC == kSrcCen ? 16 : 8), adr_g3 = R.adr_g3 + g0 * (SRC == kSrcCen ? 16 : 8);
+  tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_g2, adr_g3, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy,
                                                                   cx_lane, S);
   if constexpr (CNT > SUB)
-    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, SUB, (CNT < 2 * SUB ? CNT : 2 * SUB)>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel,
+    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, SUB, (CNT < 2 * SUB ? CNT : 2 * SUB)>(A, lut, R, g0, adr_o, adr_g, adr_g2, adr_g3, adr_p, off_g, Ip, pa, Gg, qxg, e_rel,
                                                                               e_span, qy, cx_lane, S);
   if constexpr (CNT > 2 * SUB)
-    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 2 * SUB, CNT>(A, lut, R, g0, adr_o, adr_g, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy, cx_lane, S);
+    tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 2 * SUB, CNT>(A, lut, R, g0, adr_o, adr_g, adr_g2, adr_g3, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy, cx_lane, S);
 }
 
 // One window row of one level for all 64 lanes -> row total R (ROWTREE7: seven interleaved partial sums, combined left to right)
@@ -409,6 +412,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   R.adr_o = strip_a + (L.pad + cx - A.half - s_lo) * 16 - ((VIEW == 0 && SRC != kSrcImg) ? 16 : 0);
   R.adr_g = ostrip_a + (cx - cmin) * (SRC == kSrcCen ? 16 : 8);
   R.adr_p = ostrip_a + ctx.ocap * 8 + (cx - cmin) * 4;
+  R.adr_g2 = R.adr_g3 = R.adr_g;
+  asm volatile("" : "+v"(R.adr_g2));
+  asm volatile("" : "+v"(R.adr_g3));
   R.lane_off = (L.pad + cx - A.half) * E;
   R.img_base = staged ? strip_a + (L.pad - s_lo) * 16 : L.pad * E;
   R.fx_lo = staged ? s_lo - L.pad : -L.pad;
