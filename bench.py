@@ -29,24 +29,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BYTES_PER_TAP = 19  # 3 B guide pixel + 2 x 8 B cost cells per window tap (f64 volume)
+OPS_PER_TAP = 14    # algorithmic f64 lane-operations per window tap (an FMA counts once)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# VALU issue: one wave64 instruction occupies its SIMD for 4.1 shader cycles, f64 and 32-bit alike (measured:
-# tools/ubench/valu_issue.hip, profiles/r02_valu_issue.txt; = the guide's 78.6 TFLOP/s f64 vector peak, 2 flop per lane
-# per FMA); 256 CUs x 4 SIMDs.  The shader clock under this kernel is taken from the same PMC run as the instruction count.
-VALU_CYCLES_PER_WINSTR = 4.1
+# The binding resource is VALU issue (the tap stream never leaves the chip: measured HBM traffic is ~2 % of the algorithmic
+# bytes).  Peak = the guide's f64 vector rate: 78.6 TFLOP/s = 3.93e13 lane-operations/s (an FMA = 2 flop = ONE operation)
+# = 1024 SIMDs x 16 lanes x 2.4 GHz = one wave64 instruction per SIMD every 4.0 cycles (measured 4.1: profiles/*valu_issue*).
+F64_LANE_OPS_PEAK = 78.6e12 / 2.0
+VALU_CYCLES_PER_WINSTR = 4.0
 N_SIMD = 1024
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_refine_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "refine_pmc.json")  # SQ_INSTS_VALU etc. of k_refine, stamped with the kernel sources' hash
 
 
-def cpu_baseline(device_index=0):
+def kernel_source_hash():
+    """sha256 over the device sources: a committed PMC file is only quoted while it describes the kernels that are being timed"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "crossscalepatchmatch_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_on(name, device_index=0):
     """The oracle (kind "port": the reference itself needs OpenCV/gflags and cannot be built here) in REFERENCE ORDER
-    (serial raster sweep, serial window sum, OpenMP over the rows of init/refinement as the reference) on the whole of
-    BASELINE.json configs[0] (C1: 450x375, max_dis=60, GRD, single scale) on this box's host cores, next to the GPU on the
-    same pair, seed and schedule -- which also gives the north-star parity figure (disparities within 0.5 px)."""
+    (serial raster sweep, serial window sum, OpenMP over the rows of init/refinement as the reference) on the whole of one
+    BASELINE.json config on this box's host cores, next to the GPU on the same pair, seed and schedule -- which also gives
+    the north-star parity figure (disparities within 0.5 px of the reference-order CPU result)."""
     from oracle import pyoracle as po
     import crossscalepatchmatch_amd as cs
     from crossscalepatchmatch_amd import synth
-    cfg, l, r, _, _ = synth.make_config("C1")
+    cfg, l, r, _, _ = synth.make_config(name)
     threads = max(1, min(os.cpu_count() or 1, cfg["h"]))
     t0 = time.perf_counter()
     pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
@@ -70,15 +84,27 @@ def cpu_baseline(device_index=0):
     mpix = cfg["w"] * cfg["h"] / 1e6
     return {
         "value": mpix / dt, "unit": "Mpix/s", "cores": threads, "kind": "port",
-        "sample": f"the whole of C1 (BASELINE.json configs[0]): {cfg['w']}x{cfg['h']} max_dis={cfg['max_dis']} GRD single scale, 3 iterations, "
+        "sample": f"the whole of {name}: {cfg['w']}x{cfg['h']} max_dis={cfg['max_dis']} GRD "
+                  f"{'cross-scale (5 levels, lambda 0.3)' if cfg['scale_num'] else 'single scale'}, 3 iterations, "
                   f"reference order (serial raster sweep, serial window sum), OpenMP over the rows of init/refinement as the reference; "
                   f"{dt:.1f} s, {taps / dt / 1e9:.3f} Gtap/s",
         "seconds": dt,
         "gpu_same_workload": {"value": mpix / gdt, "unit": "Mpix/s", "seconds": gdt, "note": "host buffers in, PCIe included"},
+        "gpu_vs_cpu_within0.5px": float(np.mean([np.mean(d <= 0.5) for d in diff])),
         "gpu_vs_cpu_bad0.5": float(np.mean([np.mean(d > 0.5) for d in diff])),
         "gpu_vs_cpu_bad2.0": float(np.mean([np.mean(d > 2.0) for d in diff])),
         "gpu_vs_cpu_max_abs_px": float(max(d.max() for d in diff)),
     }
+
+
+def cpu_baseline(device_index=0):
+    """BASELINE.json's metric is quoted on the cross-scale cost: the CPU leg runs the whole of C2 (configs[1], 450x375, D=60,
+    5 levels -- the reference's cross-scale path pre_cs_pc.cc:133-188; 1-2 minutes of host time) and, as before, the whole of
+    C1 (configs[0], single scale, the reference's own CPU-runnable case)."""
+    out = cpu_baseline_on("C2", device_index)
+    out["sample"] += " (BASELINE.json configs[1])"
+    out["c1_single_scale"] = cpu_baseline_on("C1", device_index)
+    return out
 
 
 def main():
@@ -86,7 +112,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C5 (crossscalepatchmatch_amd/synth.py)")
+    ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C4 | C5 (crossscalepatchmatch_amd/synth.py); C4 = the batch of C3-shaped pairs "
+                                                   "held by rank 0 and dispatched through crossscalepatchmatch_amd.batch.run_batch")
+    ap.add_argument("--same-pair", action="store_true", help="time one pair K times instead of K distinct pairs (seeds base + k)")
     ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)
@@ -140,30 +168,62 @@ def main():
             dist.init_process_group(backend)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    cfg, l, r, gl, gr = synth.make_config(args.config, index=rank)
+    # K distinct pairs per rank (seeds base + i), all resident in HBM before the timed region starts.
+    # C4 (BASELINE.json configs[3]): rank 0 holds the WHOLE batch (K pairs per rank x world) and batch.run_batch dispatches it
+    # (parameter broadcast, chunked scatter, per-rank contexts in flight, gather of the maps) inside the timed region.
+    batch_mode = args.config == "C4"
+    npairs = 1 if args.same_pair else args.steps
+    first = rank * npairs
+    if batch_mode and rank == 0 and not args.same_pair:
+        first, npairs = 0, args.steps * world
+    host_pairs = [synth.make_config(args.config, index=first + k) for k in range(npairs)]
+    cfg, _, _, gl, gr = host_pairs[(args.steps - 1) % npairs]  # ground truth of the LAST timed pair (checked below)
     w, h = cfg["w"], cfg["h"]
-    d_l = torch.from_numpy(l).to(dev)
-    d_r = torch.from_numpy(r).to(dev)
+    use_pp = bool(cfg.get("use_pp"))
+    d_pairs = [(torch.from_numpy(p[1]).to(dev), torch.from_numpy(p[2]).to(dev)) for p in host_pairs]
     torch.cuda.synchronize()
     from crossscalepatchmatch_amd import capi
     nfl = max(1, min(args.in_flight, args.steps))
-    ctxs = [cs.StereoContext(dev_index) for _ in range(nfl)]  # each context owns a HIP stream
+    pair_fn = None
+    if batch_mode:
+        from crossscalepatchmatch_amd import batch
+        pair_fn = batch.HipPairFn(dev_index, in_flight=nfl)
+        ctxs = pair_fn.ctxs
+        batch_dev = dev if backend == "nccl" else torch.device("cpu")  # the collectives' side: RCCL moves device tensors, gloo host tensors
+        batch_pairs = torch.stack([torch.stack(p) for p in d_pairs]).to(batch_dev) if rank == 0 else None  # [n, 2, h, w, 3], resident before the timed region
+        batch_params = dict(w=w, h=h, max_dis=cfg["max_dis"], dis_scale=cfg["dis_scale"], scale_num=cfg["scale_num"], reg_lambda=cfg["reg_lambda"],
+                            iters=3, seed=12345, schedule=0 if args.schedule == "raster" else 1, use_pp=int(use_pp), cc=batch.CC_CODES[args.cc])
+
+        class _ViaHost:  # gloo control plane (CSPM_BENCH_BACKEND=gloo, ranks sharing a GPU): blocks arrive as host tensors
+            def __call__(self, l, r, p):
+                dl, dr = pair_fn(l.to(dev).contiguous(), r.to(dev).contiguous(), p)
+                pair_fn.order_after_pairs()
+                return dl.cpu(), dr.cpu()
+
+            def finalize(self):
+                pair_fn.finalize()
+    else:
+        ctxs = [cs.StereoContext(dev_index) for _ in range(nfl)]  # each context owns a HIP stream
     d_out = [[torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(nfl)]
     for ctx in ctxs:
         ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
     sched = cs.SCHED_RASTER if args.schedule == "raster" else cs.SCHED_REDBLACK
     pm_kw = dict(seed=12345, schedule=sched, rb_rounds=args.rb_rounds, rb_neighbours=4, early_exit=0 if args.no_early_exit else 1)
 
-    def step(k):
+    def step(k, pair=None):
         ctx, out = ctxs[k % nfl], d_out[k % nfl]  # everything below is enqueued on the context's stream, nothing waits
+        d_l, d_r = d_pairs[(k if pair is None else pair) % npairs]
         ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
         if args.cc == "IMG":
             ctx.build_cost_img(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
         else:
             (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
         ctx.patchmatch(3, **pm_kw)
-        for v in (0, 1):
-            ctx.disparity_u8_device(v, cfg["dis_scale"], out[v].data_ptr())
+        if use_pp:  # PatchMatch(iter_num, plane_cost, use_pp = true): post-processing is inside the reference's timed region (main.cc:92-126)
+            ctx.postprocess_device(cfg["dis_scale"], out[0].data_ptr(), out[1].data_ptr())
+        else:
+            for v in (0, 1):
+                ctx.disparity_u8_device(v, cfg["dis_scale"], out[v].data_ptr())
 
     def sync_all():
         for ctx in ctxs:
@@ -173,16 +233,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    def run_batch_once(count_per_rank):
+        sub = batch_pairs[: count_per_rank * world] if rank == 0 else None
+        fn = pair_fn if batch_dev.type == "cuda" else _ViaHost()
+        return batch.run_batch(sub, batch_params if rank == 0 else None, fn, device=str(batch_dev), dist=dist)
+
+    if batch_mode:
+        if args.warmup:
+            run_batch_once(min(args.warmup, args.steps))
+    else:
+        for k in range(args.warmup):
+            step(k, pair=npairs - 1 - k % npairs)  # warm-up on pairs from the END of the list: the timed region starts on inputs not seen yet
     for ctx in ctxs:
         ctx.synchronize()
         ctx.enable_timing(not args.no_kernel_timing)
         ctx.reset_timing()
     sync_all()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    if batch_mode:
+        batch_maps = run_batch_once(args.steps)  # dispatch + compute + gather: the whole of configs[3]
+    else:
+        for k in range(args.steps):
+            step(k)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -203,7 +275,7 @@ def main():
     if nfl > 1:
         ctxs[0].enable_timing(not args.no_kernel_timing)
         ctxs[0].reset_timing()
-        step(0)
+        step(0, pair=args.steps - 1)
         ctxs[0].synchronize()
         solo = ctxs[0].timing()
         ctxs[0].enable_timing(False)
@@ -214,50 +286,64 @@ def main():
         alg_taps = 2 * ctx.taps_per_view_pass()              # one evaluation of every pixel of both views (in-image window taps)
         exe_taps = 2 * ctx.row_engine_taps_per_view_pass()   # lane-taps the row engine executes for it
         out = {
-            "metric": "Mpix/s disparity (%s, use_cs=true)" % args.cc, "value": mpix, "unit": "Mpix/s", "n_gpus": world,
+            "metric": "Mpix/s disparity (%s, use_cs=%s)" % (args.cc, "true" if cfg["scale_num"] else "false"), "value": mpix, "unit": "Mpix/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {w}x{h} max_dis={cfg['max_dis']} GRD scale_num={cfg['scale_num']} "
                                    f"reg_lambda={cfg['reg_lambda']} wnd=35 iters=3 (BASELINE.json configs[2] when C3)",
                        "cc_name": args.cc, "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule,
                        "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds,
-                       "early_exit": not args.no_early_exit, "pairs_per_gpu": args.steps, "pairs_in_flight_per_gpu": nfl,
-                       "parallelism": f"{world} rank(s), one per GPU, {nfl} independent pair stream(s) each"},
+                       "early_exit": not args.no_early_exit, "pairs_per_gpu": args.steps, "distinct_pairs_per_gpu": npairs, "pairs_in_flight_per_gpu": nfl, "use_pp": use_pp,
+                       "parallelism": f"{world} rank(s), one per GPU, {nfl} independent pair stream(s) each",
+                       "dispatch": ("batch.run_batch: rank 0 holds the %d pairs; broadcast of the parameters, chunked scatter of the pair blocks, "
+                                    "gather of the 8-bit maps -- all inside the timed region" % (args.steps * world)) if batch_mode else
+                                   "every rank generates its own pairs (no collective in the timed region)"},
         }
         ref = solo["refine"]
         if ref["launches"]:
             # the dominant kernel: k_refine = all halving steps of one PlaneRefinement iteration (cs_patchmatch.cc:292-345)
             avg_s = ref["ms"] / ref["launches"] / 1e3
             steps_per_launch = ref["evals"] / ref["launches"] / (2 * w * h)
-            alg_bytes = alg_taps * steps_per_launch * BYTES_PER_TAP
+            taps_launch = alg_taps * steps_per_launch
+            alg_bytes = taps_launch * BYTES_PER_TAP
+            alg_ops = taps_launch * OPS_PER_TAP
             roof = {
                 "kernel": "k_refine (row engine; one launch = the %d halving steps of one PlaneRefinement iteration)" % round(steps_per_launch),
                 "avg_launch_ms": avg_s * 1e3, "launches": ref["launches"],
                 "measured": "hipEvents on the context stream; " + ("one extra pair alone on the GPU after the timed region (kernels of overlapping "
                                                                      "pairs are not separable)" if nfl > 1 else "the timed region"),
-                "algorithmic_taps_per_launch": alg_taps * steps_per_launch, "executed_lane_taps_per_launch": exe_taps * steps_per_launch,
-                "executed_vs_algorithmic_taps": exe_taps / alg_taps,
+                # the roofline of SURVEY.md 8(d): ALGORITHMIC operations (14 per in-image window tap, as the reference performs them)
+                # per launch / the launch duration measured here, against the chip's f64 vector rate
+                "bound": "valu_issue", "achieved": alg_ops / avg_s / 1e12, "peak": F64_LANE_OPS_PEAK / 1e12, "unit": "T f64 lane-op/s",
+                "frac": alg_ops / avg_s / F64_LANE_OPS_PEAK,
+                "algorithmic_ops_per_tap": OPS_PER_TAP,
+                "algorithmic_taps_per_launch": taps_launch, "executed_lane_taps_per_launch": exe_taps * steps_per_launch,
+                "executed_vs_algorithmic_taps": exe_taps / alg_taps, "taps_per_s": taps_launch / avg_s,
+                # the HBM yardstick next to it: > 1 x peak only says that the tap stream is served on chip
                 "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBs": alg_bytes / avg_s / 1e9,
-                "taps_per_s": alg_taps * steps_per_launch / avg_s,
+                "algorithmic_hbm_frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "note": "bound = VALU issue: the tap stream never leaves the chip (see traffic vs algorithmic_bytes_per_launch), HBM at %.1f x its "
+                        "peak by the algorithmic-byte yardstick.  frac = algorithmic f64 operations (14 per tap x in-image taps of one launch) / "
+                        "launch time / 3.93e13 lane-op/s (78.6 TFLOP/s f64 vector, an FMA counted once)." % (alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS),
             }
+            # instruction-level view of the same launch from the committed rocprofv3 --pmc passes -- quoted only while the file
+            # describes the kernels being timed (source hash) and the headline workload
             pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else None
-            if pmc and args.config == "C3" and args.cc == "GRD" and not args.volumes:
+            if pmc and pmc.get("kernel_source_hash") == kernel_source_hash() and args.config in ("C3", "C4") and args.cc == "GRD" and not args.volumes:
                 winstr = pmc["valu_winstr_per_launch"]
                 peak = N_SIMD * pmc["shader_clock_ghz"] * 1e9 / VALU_CYCLES_PER_WINSTR
                 roof.update({
-                    "bound": "valu_issue", "achieved": winstr / avg_s / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
-                    "frac": winstr / avg_s / peak,
                     "traffic": pmc["hbm_bytes_per_launch"], "hbm_frac_of_peak": pmc["hbm_bytes_per_launch"] / avg_s / 1e9 / HBM_PEAK_GBS,
-                    "lds_busy_frac_pmc": pmc["lds_busy_frac"], "valu_winstr_per_64_algorithmic_taps": winstr / (alg_taps * steps_per_launch / 64),
-                    "note": "The tap stream is served on chip (measured HBM traffic is %.1f %% of the algorithmic bytes), so the "
-                            "bound is not HBM.  bound = VALU issue: achieved = VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU of "
-                            "the same command, profiles/r02_refine_pmc.json) / the launch time measured here; peak = 1024 SIMDs x shader "
-                            "clock / 4.1 cycles per wave-instruction (tools/ubench/valu_issue.hip).  The LDS (strips + tables) is the "
-                            "second resource, lds_busy_frac_pmc." % (100.0 * pmc["hbm_bytes_per_launch"] / alg_bytes),
+                    "valu_busy_frac": winstr / avg_s / peak, "valu_winstr_per_launch_pmc": winstr,
+                    "valu_winstr_per_64_algorithmic_taps": winstr / (taps_launch / 64),
+                    "lds_busy_frac_pmc": pmc["lds_busy_frac"], "pmc_file": os.path.relpath(PMC_FILE, ROOT),
+                    "pmc_note": "valu_busy_frac = SQ_INSTS_VALU per launch (rocprofv3 --pmc of this command, committed file, same kernel-source "
+                                "hash) x 4.0 cycles / 1024 SIMDs / the shader cycles of the launch timed here",
                 })
             else:
-                roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instr/s", "frac": None, "traffic": None,
-                             "note": "instruction counts are committed for the headline workload only (C3, GRD, fused)"})
+                roof["pmc_note"] = ("no committed PMC file for these kernels (source hash mismatch or another workload): instruction-level "
+                                    "figures omitted rather than quoted stale")
             out["roofline"] = roof
         out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}  # with pairs in flight: overlapping brackets
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}
@@ -265,12 +351,20 @@ def main():
             out["kernel_ms_one_pair_alone"] = {k: v["ms"] for k, v in solo.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
             out["cpu_baseline"] = cpu_baseline(dev_index)
-        # sanity of the result that was timed (not part of the timed region)
-        dl = ctx.disparity_f64(0)
-        out["bad2_vs_gt_left"] = synth.bad_fraction(dl, gl, 2.0)
+        # sanity of the LAST pair that was timed (not part of the timed region)
+        if batch_mode:  # rank 0's last own pair: index steps-1 of the batch; its 8-bit map came back through the gather
+            gl = host_pairs[min(args.steps, npairs) - 1][3]
+            out["bad2_vs_gt_left"] = synth.bad_fraction(batch_maps[min(args.steps, npairs) - 1, 0].cpu().numpy().astype(np.float64) / cfg["dis_scale"], gl, 2.0)
+        else:
+            last = ctxs[(args.steps - 1) % nfl]
+            out["bad2_vs_gt_left"] = synth.bad_fraction(last.disparity_f64(0), gl, 2.0)
+        out["distinct_pairs"] = npairs
         print(json.dumps(out))
-    for ctx in ctxs:
-        ctx.close()
+    if pair_fn is not None:
+        pair_fn.close()
+    else:
+        for ctx in ctxs:
+            ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

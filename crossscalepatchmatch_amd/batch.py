@@ -14,7 +14,8 @@ import os
 
 import numpy as np
 
-PARAM_KEYS = ("w", "h", "max_dis", "dis_scale", "scale_num", "reg_lambda", "iters", "seed", "schedule", "use_pp")
+PARAM_KEYS = ("w", "h", "max_dis", "dis_scale", "scale_num", "reg_lambda", "iters", "seed", "schedule", "use_pp", "cc")
+CC_CODES = {"GRD": 0, "CEN": 1, "IMG": 2}  # params["cc"]: the cost family (cc/grd_cc, cc/cen_cc; IMG = GrdPC / CSPC)
 
 
 def partition(n_items, world, rank):
@@ -31,48 +32,86 @@ def block_sizes(n_items, world):
 class HipPairFn:
     """(l_bgr, r_bgr) torch uint8 tensors on the rank's GPU -> (l_dis, r_dis) torch uint8 tensors, via the C ABI.
 
-    Stream ordering: libcspm runs on a stream of its own (a torch side stream handed to cspm_set_stream).  Before a pair
-    is enqueued that stream waits (device-side) for torch's current stream -- the one the NCCL/RCCL scatter was ordered
-    into by ProcessGroupNCCL.wait() -- so k_pack_bgr never reads a half-received input block; after the pair, torch's
-    current stream waits for the libcspm stream, so the gather that follows sees finished maps.  No host synchronisation
-    per pair."""
+    `in_flight` contexts, each with a HIP stream of its own, take the pairs round-robin: a pair's latency-bound raster sweep and
+    the tail of every launch leave CUs idle that the next pair's kernels use (the same arrangement as bench.py).  Nothing
+    waits on the host per pair -- finalize() synchronises every context once, which is also where an error inside an
+    asynchronous run (a sweep that timed out with more than one pair enqueued) is raised.
 
-    def __init__(self, device_index):
+    Stream ordering: before a pair is enqueued its stream waits (device-side) for torch's current stream -- the one the
+    NCCL/RCCL scatter was ordered into by Work.wait() -- so k_pack_bgr never reads a half-received input block.  The pair
+    writes its maps straight into the caller's output views (`out=`); torch's current stream is NOT made to wait per pair
+    (that would chain the pairs of different contexts one after the other): run_batch calls order_after_pairs() before it
+    lets a collective overwrite a receive buffer, and finalize() before it reads the maps."""
+    writes_out = True
+
+    def __init__(self, device_index, in_flight=3):
         import torch
         from .capi import StereoContext
         self.device = torch.device("cuda", device_index)
-        self.ctx = StereoContext(device_index)  # raises CspmError without libcspm_hip.so / a gfx950 device
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.ctx.set_stream(self.stream.cuda_stream)
+        self.ctxs = [StereoContext(device_index) for _ in range(max(1, int(in_flight)))]  # raises CspmError without libcspm_hip.so / a device
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.ctxs]
+        for c, st in zip(self.ctxs, self.streams):
+            c.set_stream(st.cuda_stream)
+        self.calls = 0
+        self.ctx = self.ctxs[0]
 
-    def __call__(self, l, r, p):
+    def __call__(self, l, r, p, out=None):
         import torch
         h, w = int(p["h"]), int(p["w"])
         assert l.is_cuda and l.device == self.device and l.is_contiguous() and r.is_contiguous()
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        self.ctx.set_images_device(l.data_ptr(), r.data_ptr(), w, h, w * 3)
-        self.ctx.build_cost_grd(int(p["max_dis"]), 35, int(p["scale_num"]), float(p["reg_lambda"]))
-        self.ctx.patchmatch(int(p["iters"]), seed=int(p["seed"]), schedule=int(p["schedule"]))
+        k = self.calls % len(self.ctxs)
+        self.calls += 1
+        ctx, stream = self.ctxs[k], self.streams[k]
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        ctx.set_images_device(l.data_ptr(), r.data_ptr(), w, h, w * 3)
+        cc = int(p.get("cc", 0))
+        args = (int(p["max_dis"]), 35, int(p["scale_num"]), float(p["reg_lambda"]))
+        if cc == CC_CODES["IMG"]:
+            ctx.build_cost_img(*args)
+        elif cc == CC_CODES["CEN"]:
+            ctx.build_cost_cen(*args)
+        else:
+            ctx.build_cost_grd(*args)
+        ctx.patchmatch(int(p["iters"]), seed=int(p["seed"]), schedule=int(p["schedule"]))
+        if out is None:
+            out = [torch.empty((h, w), dtype=torch.uint8, device=l.device) for _ in range(2)]
+        assert all(o.is_contiguous() and o.device == self.device and o.dtype == torch.uint8 for o in out)
+        for t in (out[0], out[1], l, r):
+            t.record_stream(stream)
         if int(p["use_pp"]):
-            lo, ro = self.ctx.postprocess(int(p["dis_scale"]))  # synchronises (host buffers)
-            return torch.from_numpy(lo).to(l.device), torch.from_numpy(ro).to(l.device)
-        out = [torch.empty((h, w), dtype=torch.uint8, device=l.device) for _ in range(2)]
-        for v in (0, 1):
-            out[v].record_stream(self.stream)
-            self.ctx.disparity_u8_device(v, int(p["dis_scale"]), out[v].data_ptr())
-        l.record_stream(self.stream)
-        r.record_stream(self.stream)
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            ctx.postprocess_device(int(p["dis_scale"]), out[0].data_ptr(), out[1].data_ptr())
+        else:
+            for v in (0, 1):
+                ctx.disparity_u8_device(v, int(p["dis_scale"]), out[v].data_ptr())
         return out[0], out[1]
 
+    def order_after_pairs(self):
+        """torch's current stream waits (device-side) for everything enqueued on the pair streams so far"""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def finalize(self):
+        """host-synchronise every context: raises if anything inside the asynchronous runs failed"""
+        for c in self.ctxs:
+            c.synchronize()
+
     def close(self):
-        self.ctx.synchronize()  # also reports a raster sweep that timed out
-        self.ctx.close()
+        try:
+            self.finalize()
+        finally:
+            for c in self.ctxs:
+                c.close()
 
 
-def run_batch(pairs, params, pair_fn, device="cpu", dist=None):
+def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4):
     """pairs: on rank 0 a uint8 array/tensor [n, 2, h, w, 3] (ignored elsewhere); params: dict with PARAM_KEYS on
-    rank 0.  Returns on rank 0 a uint8 tensor [n, 2, h, w] (disparity maps in input order), None on other ranks."""
+    rank 0 ("cc" optional).  Returns on rank 0 a uint8 tensor [n, 2, h, w] (disparity maps in input order), None on other ranks.
+
+    Dispatch: every rank owns a contiguous block of pairs.  The blocks travel in rounds of `chunk_pairs` pairs per rank
+    (one scatter per round, the next round's scatter in flight while this round's pairs are being enqueued), straight out of
+    rank 0's copy of the batch: no per-rank padded staging copies, receive memory bounded by two chunks."""
     import torch
     if dist is None or not dist.is_initialized():
         world, rank = 1, 0
@@ -83,7 +122,7 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None):
     meta = torch.zeros(len(PARAM_KEYS) + 1, dtype=torch.float64, device=dev)
     if rank == 0:
         n = int(pairs.shape[0])
-        meta = torch.tensor([float(params[k]) for k in PARAM_KEYS] + [float(n)], dtype=torch.float64, device=dev)
+        meta = torch.tensor([float(params.get(k, 0)) for k in PARAM_KEYS] + [float(n)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.broadcast(meta, src=0)
     p = {k: meta[i].item() for i, k in enumerate(PARAM_KEYS)}
@@ -91,29 +130,58 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None):
     h, w = int(p["h"]), int(p["w"])
     sizes = block_sizes(n, world)
     cap = max(sizes) if sizes else 0
-    # 2. scatter the input blocks (padded to the largest block so every rank receives the same shape)
-    mine = torch.zeros((cap, 2, h, w, 3), dtype=torch.uint8, device=dev)
-    if world > 1:
-        chunks = None
-        if rank == 0:
-            src = torch.as_tensor(pairs, dtype=torch.uint8).to(dev)
-            chunks = []
-            for r in range(world):
-                a, b = partition(n, world, r)
-                c = torch.zeros((cap, 2, h, w, 3), dtype=torch.uint8, device=dev)
-                c[: b - a] = src[a:b]
-                chunks.append(c)
-        dist.scatter(mine, chunks, src=0)
-    else:
-        mine = torch.as_tensor(pairs, dtype=torch.uint8).to(dev)
-    # 3. the hot path, pair by pair, no communication
+    first = partition(n, world, rank)[0]
     out = torch.zeros((cap, 2, h, w), dtype=torch.uint8, device=dev)
-    for i in range(sizes[rank]):
-        q = dict(p)
-        q["seed"] = int(p["seed"]) + partition(n, world, rank)[0] + i  # per-pair seed = global pair index
-        dl, dr = pair_fn(mine[i, 0].contiguous(), mine[i, 1].contiguous(), q)
-        out[i, 0], out[i, 1] = dl, dr
-    # 4. gather the 8-bit maps on rank 0
+
+    def compute(block, base, count):  # the hot path, pair by pair, no communication
+        for i in range(count):
+            q = dict(p)
+            q["seed"] = int(p["seed"]) + first + base + i  # per-pair seed = global pair index
+            if getattr(pair_fn, "writes_out", False):  # the maps land in `out` directly, nothing is ordered into torch's stream
+                pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q, out=(out[base + i, 0], out[base + i, 1]))
+            else:
+                dl, dr = pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q)
+                out[base + i, 0], out[base + i, 1] = dl, dr
+
+    if world > 1:
+        chunk = max(1, min(int(chunk_pairs), cap)) if cap else 1
+        rounds = (cap + chunk - 1) // chunk
+        src = torch.as_tensor(pairs, dtype=torch.uint8).to(dev) if rank == 0 else None
+        filler = torch.zeros((chunk, 2, h, w, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+        recv = [torch.zeros((chunk, 2, h, w, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        staged = {}
+
+        def issue(j):
+            lst = None
+            if rank == 0:
+                lst = []
+                for r in range(world):
+                    a = partition(n, world, r)[0] + j * chunk
+                    cnt = max(0, min(chunk, sizes[r] - j * chunk))
+                    if cnt == chunk:
+                        lst.append(src[a:a + chunk])  # a view of the batch: nothing is copied on rank 0
+                    else:                             # the ragged tail of a block: the one staged piece per round
+                        t = staged.setdefault((j, r), filler.clone() if cnt else filler)
+                        if cnt:
+                            t[:cnt] = src[a:a + cnt]
+                        lst.append(t)
+            return dist.scatter(recv[j % 2], lst, src=0, async_op=True)
+
+        work = issue(0) if rounds else None
+        for j in range(rounds):
+            work.wait()
+            if j >= 1 and hasattr(pair_fn, "order_after_pairs"):
+                pair_fn.order_after_pairs()  # round j+1 lands in the buffer round j-1's pairs read
+            nxt = issue(j + 1) if j + 1 < rounds else None
+            compute(recv[j % 2], j * chunk, max(0, min(chunk, sizes[rank] - j * chunk)))
+            work = nxt
+    else:
+        compute(torch.as_tensor(pairs, dtype=torch.uint8).to(dev), 0, sizes[rank])
+    # errors inside the asynchronous runs surface here, before any map is handed on
+    fin = getattr(pair_fn, "finalize", None)
+    if fin is not None:
+        fin()
+    # 2. gather the 8-bit maps on rank 0
     if world > 1:
         got = [torch.zeros_like(out) for _ in range(world)] if rank == 0 else None
         dist.gather(out, got, dst=0)
@@ -135,6 +203,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--schedule", type=int, default=0)
     ap.add_argument("--use_pp", type=int, default=0)
+    ap.add_argument("--cc", default="GRD", choices=sorted(CC_CODES))
+    ap.add_argument("--in-flight", type=int, default=3)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,14 +219,14 @@ def main():
         pairs = np.stack([np.stack(synth.make_pair(cfg["w"], cfg["h"], cfg["max_dis"], cfg["regions"], cfg["seed"] + i)[:2])
                           for i in range(args.pairs)])
         params = dict(w=cfg["w"], h=cfg["h"], max_dis=cfg["max_dis"], dis_scale=cfg["dis_scale"], scale_num=cfg["scale_num"],
-                      reg_lambda=cfg["reg_lambda"], iters=3, seed=12345, schedule=args.schedule, use_pp=args.use_pp)
-    fn = HipPairFn(local_rank)
+                      reg_lambda=cfg["reg_lambda"], iters=3, seed=12345, schedule=args.schedule, use_pp=args.use_pp, cc=CC_CODES[args.cc])
+    fn = HipPairFn(local_rank, in_flight=args.in_flight)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_batch(pairs, params, fn, device=f"cuda:{local_rank}", dist=dist if world > 1 else None)
-    fn.ctx.synchronize()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fn.close()
     if rank == 0:
         print(f"{args.pairs} pairs of {cfg['w']}x{cfg['h']} on {world} GPU(s): {dt:.2f} s end to end incl. dispatch, "
               f"{args.pairs * cfg['w'] * cfg['h'] / dt / 1e6:.3f} Mpix/s, result {tuple(out.shape)}")

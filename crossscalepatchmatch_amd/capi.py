@@ -11,21 +11,23 @@ _SO = os.environ.get("CSPM_LIB") or os.path.join(_HERE, "libcspm_hip.so")  # CSP
 
 SCHED_RASTER, SCHED_REDBLACK = 0, 1
 RNG_PER_PIXEL, RNG_ROW_SHARED = 0, 1
-K_GRD, K_INIT, K_SPATIAL, K_VIEW, K_REFINE, K_MISC = range(6)
-K_NAMES = ["grd", "init", "spatial", "view", "refine", "misc"]
+K_GRD, K_INIT, K_SPATIAL, K_VIEW, K_REFINE, K_MISC, K_POST = range(7)
+K_NAMES = ["grd", "init", "spatial", "view", "refine", "misc", "post"]
 MAX_LEVELS = 8
 OPT_GRD_VOLUMES = 1
 OPT_RASTER_LAUNCHES = 2
+OPT_SWEEP_TIMEOUT_MS = 3
+OPT_SWEEP_FALLBACKS = 4
 
 # every symbol include/cspm.h declares
 SYMBOLS = [
     "cspm_device_count", "cspm_create", "cspm_destroy", "cspm_last_error", "cspm_set_stream", "cspm_synchronize",
-    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_build_cost_cen", "cspm_build_cost_img", "cspm_cen_build_cv_host", "cspm_set_option", "cspm_begin_cost", "cspm_upload_cost_slab",
+    "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_build_cost_cen", "cspm_build_cost_img", "cspm_cen_build_cv_host", "cspm_set_option", "cspm_get_option", "cspm_begin_cost", "cspm_upload_cost_slab",
     "cspm_finish_cost", "cspm_get_levels", "cspm_get_level_dims", "cspm_get_level_image", "cspm_get_cost_slab",
     "cspm_get_max_cost", "cspm_get_scale_weights", "cspm_grd_build_cv_host", "cspm_plane_cost_batch",
     "cspm_pm_default_params", "cspm_patchmatch", "cspm_pm_init", "cspm_pm_spatial", "cspm_pm_view", "cspm_pm_refine",
     "cspm_get_planes", "cspm_set_planes", "cspm_get_disparity_u8", "cspm_get_disparity_f64",
-    "cspm_disparity_u8_device", "cspm_postprocess", "cspm_enable_timing", "cspm_reset_timing", "cspm_get_timing",
+    "cspm_disparity_u8_device", "cspm_postprocess", "cspm_postprocess_device", "cspm_enable_timing", "cspm_reset_timing", "cspm_get_timing",
     "cspm_taps_per_view_pass", "cspm_row_engine_taps_per_view_pass",
 ]
 
@@ -78,6 +80,7 @@ def load_library():
         "cspm_set_images_device": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]),
         "cspm_build_cost_grd": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_set_option": (C.c_int, [vp, C.c_int, C.c_longlong]),
+        "cspm_get_option": (C.c_int, [vp, C.c_int, llp]),
         "cspm_build_cost_cen": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_build_cost_img": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double]),
         "cspm_cen_build_cv_host": (C.c_int, [C.c_int, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
@@ -104,6 +107,7 @@ def load_library():
         "cspm_get_disparity_f64": (C.c_int, [vp, C.c_int, dp]),
         "cspm_disparity_u8_device": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "cspm_postprocess": (C.c_int, [vp, C.c_int, u8p, u8p, C.c_size_t]),
+        "cspm_postprocess_device": (C.c_int, [vp, C.c_int, vp, vp]),
         "cspm_enable_timing": (C.c_int, [vp, C.c_int]),
         "cspm_reset_timing": (C.c_int, [vp]),
         "cspm_get_timing": (C.c_int, [vp, C.c_int, llp, dp, llp]),
@@ -172,6 +176,11 @@ class StereoContext:
 
     def set_option(self, key, value):
         self._chk(self.L.cspm_set_option(self.p, key, value))
+
+    def get_option(self, key):
+        v = C.c_longlong()
+        self._chk(self.L.cspm_get_option(self.p, key, C.byref(v)))
+        return v.value
 
     def build_cost_grd(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False):
         """volumes=False: fused on-the-fly GRD cells (default); True: materialised f64 cost volumes."""
@@ -294,6 +303,10 @@ class StereoContext:
         r = np.zeros((self.h, self.w), np.uint8)
         self._chk(self.L.cspm_postprocess(self.p, dis_scale, _u8(l), _u8(r), self.w))
         return l, r
+
+    def postprocess_device(self, dis_scale, d_l_ptr, d_r_ptr):
+        """PlaneToDisp + PostProcessing with device-resident outputs (asynchronous on the context's stream)"""
+        self._chk(self.L.cspm_postprocess_device(self.p, dis_scale, C.c_void_p(d_l_ptr), C.c_void_p(d_r_ptr)))
 
     # ---- measurement ----
     def enable_timing(self, on=True):

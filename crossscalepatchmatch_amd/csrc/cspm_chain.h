@@ -446,6 +446,7 @@ struct Sweep {
   unsigned long long *gran[2];  // per view, per pixel: kGranPerPixel data-tagged granules {32 bits of the final plane, epoch}
   const unsigned int *start;  // start[k] = items (both views) on diagonals < k; W+H entries
   unsigned int epoch, total;
+  long long timeout_ticks;  // bound of one wait for a predecessor, in ticks of the 100 MHz constant clock
   long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
 };
 #ifdef CSPM_SWEEP_TRACE
@@ -456,7 +457,8 @@ struct Sweep {
 
 // lanes 0..23 of one wave: lane l polls granule l % 12 of predecessor l / 12 (`need` false: nothing to wait for).  Returns the
 // wave-uniform verdict; on success `g` holds the lane's granule.
-__device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool need, unsigned int epoch, unsigned int *err, unsigned long long &g) {
+__device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool need, unsigned int epoch, unsigned int *err, long long timeout_ticks,
+                                              unsigned long long &g) {
   const long long t0 = wall_clock64();
   g = 0ull;
   for (unsigned spins = 1;; ++spins) {
@@ -466,7 +468,7 @@ __device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool 
     __builtin_amdgcn_s_sleep(1);
     if ((spins & 255u) == 0u) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      if (wall_clock64() - t0 > 300000000LL) {  // 3 s of the 100 MHz constant clock
+      if (wall_clock64() - t0 > timeout_ticks) {  // CSPM_OPT_SWEEP_TIMEOUT_MS, default 3 s
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
       }
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
       const int pred = lane >= kGranPerPixel ? 1 : 0, part = lane - pred * kGranPerPixel;
       const bool need = lane < 2 * kGranPerPixel && (pred == 0 ? have0 : have1);
       unsigned long long g;
-      const bool ok = wait_granules(sw.gran[v] + (pred == 0 ? jx : jy) * kGranPerPixel + (need ? part : 0), need, sw.epoch, &sw.ctrl[1], g);
+      const bool ok = wait_granules(sw.gran[v] + (pred == 0 ? jx : jy) * kGranPerPixel + (need ? part : 0), need, sw.epoch, &sw.ctrl[1], sw.timeout_ticks, g);
       if (lane < 2 * kGranPerPixel) reinterpret_cast<uint32_t *>(&s_plane[0][0])[lane] = (uint32_t)g;  // s_plane[pred][part / 2], half part % 2
       if (lane == 0 && !ok) s_ok = 0;
     }

@@ -1,6 +1,7 @@
 // cspm_device.h -- device-side data layout and the scalar building blocks shared by all kernels.
-// gfx950 only.  Compiled with -ffp-contract=off: every product and sum is individually rounded so
-// that results are bit-identical to the (SSE2, no-FMA) reference arithmetic restated in oracle/.
+// gfx950 only.  Compiled with -ffp-contract=off: products and sums are individually rounded like the (SSE2, no-FMA)
+// reference arithmetic, except at the sites of the tap engines where the DEVICE ORDER contracts a multiply-add by an explicit
+// fma (cspm_tap.h; the oracle's CSOR_SUM_DEVICE order does the same).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -139,14 +140,6 @@ struct Rng {
   // cv::RNG::uniform(a,b) = u*(b-a)+a
   __device__ __forceinline__ double uniform(uint32_t draw, double a, double b) const { return u01(draw) * (b - a) + a; }
 };
-
-// sum over the 64 lanes: xor butterfly with ascending offsets 1,2,4,8,16,32 (last stage of the
-// SLOT256 order of the oracle).  Every lane ends with the same bits because a+b == b+a.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
-  return v;
-}
 
 // order-preserving map double -> uint64 (for atomic min/max on costs of either sign)
 __device__ __forceinline__ unsigned long long f64_key(double v) {

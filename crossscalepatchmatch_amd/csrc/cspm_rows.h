@@ -472,7 +472,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
       const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
       const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
-      const bool safe = A.has_valid & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+      const bool safe = (L.D >= 2) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
       int f_lo = safe ? (int)fmin(q_first, q_last) : 0, f_hi = safe ? (int)fmax(q_first, q_last) + 1 : 0;
       for (int off = 1; off < kWave; off <<= 1) {
         f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
@@ -494,7 +494,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
       const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
       const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
-      const bool safe = A.has_valid & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+      const bool safe = (L.D >= 2) & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
       Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? row_taps<SRC, VIEW, false, true, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
                                                         : row_taps<SRC, VIEW, false, true>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
     } else if (staged) {

@@ -96,6 +96,10 @@ __device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
   return r;
 }
 
+// (The select of the "impossible disparity" branch is left to the compiler.  In isolation `v_cndmask_b32 .., vcc` (VOP2) occupies
+// the SIMD for ~23 cycles against 4 for the VOP3 form with the mask in an SGPR pair -- tools/ubench/valu_issue.hip -- but inside
+// the tap loop forcing the VOP3 form made k_refine 10 % slower: the masks of a tap batch then live in SGPR pairs across the
+// stages and spill; profiles/README.md, round 3.)
 // The disparity of a tap split for the interpolation between two integer disparities (:166-175).
 //   valid  <=> static_cast<int>(q_disp) in [1, D-1]  <=> 1.0 <= q_disp < D        (else the "impossible disparity" branch)
 //   f      = that integer (clamped into [1, D-1] for invalid taps, so addresses stay inside the padded rows)

@@ -18,7 +18,9 @@ class CSPatchMatch {
   // additions (the reference seeds from time(NULL) and has one schedule)
   void set_seed(uint64_t seed) { seed_ = seed; }
   void set_schedule(int schedule, int rb_rounds = 1) { schedule_ = schedule; rb_rounds_ = rb_rounds; }
-  // final plane field of a view, for callers that want sub-pixel disparities
+  // final plane field of a view, for callers that want sub-pixel disparities.  Both read the device context of the plane cost
+  // the last PatchMatch ran on: call them while that object is alive (they throw otherwise).  They return the PLANE field --
+  // PostProcessing (use_pp) works on the 8-bit maps only (cs_patchmatch.cc:508-588) and does not change it.
   void planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const;
   // unquantised disparity a*x+b*y+c of every pixel, row-major (what PlaneToDisp rounds, cs_patchmatch.cc:590-601)
   void disparity(const RefView &view, std::vector<double> *out) const;

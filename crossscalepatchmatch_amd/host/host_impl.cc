@@ -57,9 +57,21 @@ int DevicePlaneCost::device = 0;
 bool DevicePlaneCost::keep_context = false;
 cspm_ctx *DevicePlaneCost::kept_ctx_ = NULL;
 int DevicePlaneCost::kept_device_ = -1;
+std::vector<cspm_ctx *> DevicePlaneCost::live_;
+
+bool DevicePlaneCost::is_live(const cspm_ctx *ctx) {
+  for (size_t i = 0; i < live_.size(); ++i)
+    if (live_[i] == ctx) return true;
+  return false;
+}
+
+static void forget(std::vector<cspm_ctx *> &v, cspm_ctx *c) {
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == c) { v.erase(v.begin() + i); return; }
+}
 
 void DevicePlaneCost::release_kept_context() {
-  if (kept_ctx_) cspm_destroy(kept_ctx_);
+  if (kept_ctx_) { forget(live_, kept_ctx_); cspm_destroy(kept_ctx_); }
   kept_ctx_ = NULL;
   kept_device_ = -1;
 }
@@ -72,6 +84,7 @@ void DevicePlaneCost::open_context(const Mat &l_img, const Mat &r_img) {
     kept_ctx_ = NULL;
   } else {
     check(cspm_create(&ctx_, device), NULL, "cspm_create");
+    live_.push_back(ctx_);
   }
   const Mat l = l_img.clone(), r = r_img.clone();  // packed rows
   check(cspm_set_images(ctx_, l.data, r.data, l.cols, l.rows, l.step), ctx_, "cspm_set_images");
@@ -133,6 +146,7 @@ DevicePlaneCost::~DevicePlaneCost() {
     kept_ctx_ = ctx_;
     kept_device_ = ctx_device_;
   } else {
+    forget(live_, ctx_);
     cspm_destroy(ctx_);
   }
 }
@@ -180,12 +194,14 @@ void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost,
 
 void CSPatchMatch::disparity(const RefView &view, std::vector<double> *out) const {
   if (!last_ctx_) throw std::runtime_error("CSPatchMatch::disparity before PatchMatch");
+  if (!DevicePlaneCost::is_live(last_ctx_)) throw std::runtime_error("CSPatchMatch::disparity: the plane cost PatchMatch ran on has been deleted");
   out->resize((size_t)wid_ * hei_);
   check(cspm_get_disparity_f64(last_ctx_, view, out->data()), last_ctx_, "cspm_get_disparity_f64");
 }
 
 void CSPatchMatch::planes(const RefView &view, std::vector<Plane> *out, std::vector<double> *min_cost) const {
   if (!last_ctx_) throw std::runtime_error("CSPatchMatch::planes before PatchMatch");
+  if (!DevicePlaneCost::is_live(last_ctx_)) throw std::runtime_error("CSPatchMatch::planes: the plane cost PatchMatch ran on has been deleted");
   const size_t n = (size_t)wid_ * hei_;
   std::vector<double> np(6 * n), cost(n);
   check(cspm_get_planes(last_ctx_, view, np.data(), cost.data()), last_ctx_, "cspm_get_planes");

@@ -1,5 +1,6 @@
 // device_plane_cost.h -- common implementation of PreSSPC / PreCSPC / GrdPC / CSPC above the C ABI (include/cspm.h).
 #pragma once
+#include <vector>
 #include "../cc_method.h"
 #include "i_plane_cost.h"
 
@@ -18,6 +19,9 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
   // so a stream of equally sized pairs allocates once
   static bool keep_context;
   static void release_kept_context();
+  // is this context still owned by a live (or parked) DevicePlaneCost?  CSPatchMatch borrows the context of the cost object it
+  // ran on (planes(), disparity()) and must not touch it once that object is gone
+  static bool is_live(const cspm_ctx *ctx);
 
  private:
   DevicePlaneCost(const DevicePlaneCost &);
@@ -27,4 +31,5 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
   int ctx_device_;
   static cspm_ctx *kept_ctx_;
   static int kept_device_;
+  static std::vector<cspm_ctx *> live_;
 };

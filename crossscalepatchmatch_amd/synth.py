@@ -8,10 +8,12 @@ import numpy as np
 
 # BASELINE.json configs: name -> (W, H, max_dis, dis_scale, scale_num, reg_lambda, regions, seed)
 CONFIGS = {
-    "C1": dict(w=450, h=375, max_dis=60, dis_scale=4, scale_num=0, reg_lambda=0.0, regions=8, seed=1001),
-    "C2": dict(w=450, h=375, max_dis=60, dis_scale=4, scale_num=5, reg_lambda=0.3, regions=8, seed=1002),
-    "C3": dict(w=1242, h=375, max_dis=128, dis_scale=1, scale_num=5, reg_lambda=0.3, regions=12, seed=2000),
-    "C5": dict(w=3000, h=2000, max_dis=256, dis_scale=1, scale_num=5, reg_lambda=0.3, regions=24, seed=3001),
+    "C1": dict(w=450, h=375, max_dis=60, dis_scale=4, scale_num=0, reg_lambda=0.0, regions=8, seed=1001, use_pp=False),
+    "C2": dict(w=450, h=375, max_dis=60, dis_scale=4, scale_num=5, reg_lambda=0.3, regions=8, seed=1002, use_pp=False),
+    "C3": dict(w=1242, h=375, max_dis=128, dis_scale=1, scale_num=5, reg_lambda=0.3, regions=12, seed=2000, use_pp=False),
+    # C4 = 200 pairs of C3's shape, seeds 2000 + i (make_config("C4", index=i) == make_config("C3", index=i))
+    "C4": dict(w=1242, h=375, max_dis=128, dis_scale=1, scale_num=5, reg_lambda=0.3, regions=12, seed=2000, use_pp=False),
+    "C5": dict(w=3000, h=2000, max_dis=256, dis_scale=1, scale_num=5, reg_lambda=0.3, regions=24, seed=3001, use_pp=True),
 }
 
 

@@ -83,6 +83,14 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * workgroups hand pixels over through per-pixel data-tagged granules (the final plane, polled directly); 1 = one launch per anti-diagonal (W+H-2 launches
  * per sweep; same results, kept as a cross-check). */
 #define CSPM_OPT_RASTER_LAUNCHES 2
+/* CSPM_OPT_SWEEP_TIMEOUT_MS (default 3000; 0 = every wait fails at once, for tests): how long a workgroup of the persistent sweep
+ * waits for a predecessor pixel before the sweep gives up.  A timeout is slowness (shared GPU, profiler, many contexts in
+ * flight), never a wrong result: when exactly one whole cspm_patchmatch ran since the last synchronising call, that call
+ * repeats it with per-diagonal launches (identical planes) and reports success; otherwise it reports CSPM_ERR_HIP.
+ * CSPM_OPT_SWEEP_FALLBACKS (read only): how many times that happened on this context. */
+#define CSPM_OPT_SWEEP_TIMEOUT_MS 3
+#define CSPM_OPT_SWEEP_FALLBACKS 4
+int cspm_get_option(cspm_ctx *ctx, int key, long long *value);
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on
  * the device; Hamming cells are computed on the fly from the codes (default) or materialised as f64 volumes
@@ -146,6 +154,9 @@ int cspm_get_disparity_f64(cspm_ctx *ctx, int view, double *out); /* unquantised
 int cspm_disparity_u8_device(cspm_ctx *ctx, int view, int dis_scale, void *d_out);
 /* PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps */
 int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride);
+/* the same with device-resident outputs (u8, packed w*h each); asynchronous on the ctx stream like cspm_patchmatch --
+ * PatchMatch(iter_num, plane_cost, use_pp = true) without leaving the device (cs_patchmatch.cc:103-107) */
+int cspm_postprocess_device(cspm_ctx *ctx, int dis_scale, void *d_l_out, void *d_r_out);
 
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by hipEvents on the ctx stream. */
@@ -155,7 +166,8 @@ int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_ou
 #define CSPM_K_VIEW 3     /* plane cost evaluation: view propagation */
 #define CSPM_K_REFINE 4   /* plane cost evaluation: plane refinement (the dominant kernel) */
 #define CSPM_K_MISC 5     /* pyramid, resolve, disparity, ... */
-#define CSPM_K_COUNT 6
+#define CSPM_K_POST 6     /* PostProcessing: left-right check, fill, weighted median */
+#define CSPM_K_COUNT 7
 int cspm_enable_timing(cspm_ctx *ctx, int on);
 int cspm_reset_timing(cspm_ctx *ctx);
 /* launches, summed milliseconds and summed evaluated candidate planes of a kernel class */

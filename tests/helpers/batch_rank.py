@@ -18,17 +18,21 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     torch.cuda.init()
-    fn = batch.HipPairFn(0)
+    fn = batch.HipPairFn(0, in_flight=2)
 
     class OnGpu:
-        """gloo moves host tensors; the per-pair function wants its inputs in HBM and hands device tensors back"""
+        """gloo moves host tensors; the per-pair function wants its inputs in HBM and hands device tensors back (.cpu() waits
+        for torch's current stream, which order_after_pairs() puts behind the pair's stream)"""
         def __call__(self, l, r, p):
             dl, dr = fn(l.cuda(0).contiguous(), r.cuda(0).contiguous(), p)
-            fn.ctx.synchronize()
+            fn.order_after_pairs()
             return dl.cpu(), dr.cpu()
 
+        def finalize(self):
+            fn.finalize()
+
     pairs = np.load(os.path.join(out_dir, "pairs.npy")) if rank == 0 else None
-    got = batch.run_batch(pairs, PARAMS if rank == 0 else None, OnGpu(), device="cpu", dist=dist)
+    got = batch.run_batch(pairs, PARAMS if rank == 0 else None, OnGpu(), device="cpu", dist=dist, chunk_pairs=2)
     fn.close()
     if rank == 0:
         np.save(os.path.join(out_dir, "out.npy"), got.numpy())

@@ -33,14 +33,30 @@ def _fake_pair_fn(l, r, p):
     return dl.to(torch.uint8), dr.to(torch.uint8)
 
 
-def _worker(rank, world, port, n_pairs, ret):
+class _CountingFn:
+    """the stand-in with a finalize hook: run_batch must call it exactly once, after the last pair and before the gather"""
+    def __init__(self):
+        self.pairs = self.finalized = 0
+
+    def __call__(self, l, r, p):
+        assert not self.finalized
+        self.pairs += 1
+        return _fake_pair_fn(l, r, p)
+
+    def finalize(self):
+        self.finalized += 1
+
+
+def _worker(rank, world, port, n_pairs, ret, chunk=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(5)
     pairs = rng.integers(0, 256, (n_pairs, 2, 6, 9, 3)).astype(np.uint8) if rank == 0 else None
     params = dict(w=9, h=6, max_dis=16, dis_scale=4, scale_num=5, reg_lambda=0.3, iters=3, seed=100, schedule=0, use_pp=0) if rank == 0 else None
-    out = batch.run_batch(pairs, params, _fake_pair_fn, device="cpu", dist=dist)
+    fn = _CountingFn()
+    out = batch.run_batch(pairs, params, fn, device="cpu", dist=dist, chunk_pairs=chunk)
+    assert fn.finalized == 1 and fn.pairs == batch.block_sizes(n_pairs, world)[rank]
     if rank == 0:
         ret["out"] = out.numpy()
         ret["pairs"] = pairs
@@ -56,11 +72,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_pairs", [(2, 5), (3, 7), (2, 1)])
-def test_scatter_compute_gather(world, n_pairs):
+@pytest.mark.parametrize("world,n_pairs,chunk", [(2, 5, 4), (3, 7, 1), (2, 1, 4), (2, 9, 2), (3, 2, 4)])
+def test_scatter_compute_gather(world, n_pairs, chunk):
+    """rounds of `chunk` pairs per rank: blocks longer than a round, ragged last rounds, ranks with nothing to do"""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n_pairs, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, ret, chunk), nprocs=world, join=True)
     out, pairs = ret["out"], ret["pairs"]
     assert out.shape == (n_pairs, 2, 6, 9)
     p = dict(max_dis=16)

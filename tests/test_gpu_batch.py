@@ -32,22 +32,41 @@ def _direct(ctx, pairs, use_pp=0):
     return np.array(out)
 
 
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
 @pytest.mark.parametrize("use_pp", [0, 1])
-def test_run_batch_world1_on_device(gpu_ctx, use_pp):
+def test_run_batch_world1_on_device(gpu_ctx, use_pp, in_flight):
+    """1, 2 or 3 contexts in flight per rank (pairs round-robin over them, nothing waits per pair; run_batch synchronises once
+    through HipPairFn.finalize before it hands the maps on); with and without post-processing on the device."""
     import torch
     from crossscalepatchmatch_amd import batch
-    pairs = _pairs(3)
-    fn = batch.HipPairFn(0)
+    pairs = _pairs(5)
+    fn = batch.HipPairFn(0, in_flight=in_flight)
     got = batch.run_batch(pairs, dict(PARAMS, use_pp=use_pp), fn, device="cuda:0", dist=None)
-    fn.ctx.synchronize()
     torch.cuda.synchronize()
     fn.close()
     np.testing.assert_array_equal(got.cpu().numpy(), _direct(gpu_ctx, pairs, use_pp))
 
 
+def test_run_batch_cost_family(gpu_ctx):
+    """params["cc"] selects the cost family on every rank: census here"""
+    import torch
+    from crossscalepatchmatch_amd import batch
+    pairs = _pairs(2)
+    fn = batch.HipPairFn(0, in_flight=2)
+    got = batch.run_batch(pairs, dict(PARAMS, cc=batch.CC_CODES["CEN"]), fn, device="cuda:0", dist=None).cpu().numpy()
+    fn.close()
+    for i, (l, r) in enumerate(pairs):
+        gpu_ctx.set_images(l, r)
+        gpu_ctx.build_cost_cen(D, 35, PARAMS["scale_num"], PARAMS["reg_lambda"])
+        gpu_ctx.patchmatch(PARAMS["iters"], seed=PARAMS["seed"] + i, schedule=0)
+        for v in (0, 1):
+            np.testing.assert_array_equal(got[i, v], gpu_ctx.disparity_u8(v, 4))
+
+
 def test_run_batch_two_ranks_one_gpu(gpu_ctx, tmp_path):
-    """2 processes, gloo rendezvous on 127.0.0.1, both computing on cuda:0 with HipPairFn; 5 pairs -> blocks of 3 and 2."""
-    pairs = _pairs(5)
+    """2 processes, gloo rendezvous on 127.0.0.1, both computing on cuda:0 with HipPairFn (2 contexts in flight each); 7 pairs ->
+    blocks of 4 and 3, dispatched in rounds of 2 pairs per rank (the ragged last round is the staged one)."""
+    pairs = _pairs(7)
     np.save(tmp_path / "pairs.npy", pairs)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))

@@ -316,3 +316,53 @@ def test_pairs_in_flight_do_not_interfere(gpu_ctx, small_pair, mid_pair, odd_pai
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_sweep_timeout_falls_back_to_per_diagonal_launches(gpu_ctx, mid_pair):
+    """A persistent sweep that gives up waiting (CSPM_OPT_SWEEP_TIMEOUT_MS; 0 makes every longer wait fail) is slowness, not a
+    wrong result: the synchronising call repeats the one PatchMatch that ran since the last check with per-diagonal launches and
+    returns the same planes.  Several unchecked runs cannot be repeated: that is reported as an error."""
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import capi
+    ctx = cs.StereoContext(0)
+    try:
+        ctx.set_images(mid_pair["l"], mid_pair["r"])
+        ctx.build_cost_grd(mid_pair["max_dis"], 35, 5, 0.3)
+        ctx.patchmatch(2, seed=9, schedule=0)
+        want = [ctx.get_planes(v) for v in (0, 1)]
+        assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 0 and ctx.get_option(capi.OPT_SWEEP_TIMEOUT_MS) == 3000
+        ctx.set_option(capi.OPT_SWEEP_TIMEOUT_MS, 0)
+        ctx.patchmatch(2, seed=9, schedule=0)
+        got = [ctx.get_planes(v) for v in (0, 1)]  # the getter synchronises, sees the timeout and repeats the run
+        assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 1
+        for v in (0, 1):
+            np.testing.assert_array_equal(got[v][0], want[v][0])
+            np.testing.assert_array_equal(got[v][1], want[v][1])
+        ctx.patchmatch(2, seed=9, schedule=0)
+        ctx.patchmatch(2, seed=10, schedule=0)  # two runs enqueued, nothing checked in between
+        with pytest.raises(cs.CspmError, match="timed out"):
+            ctx.synchronize()
+        ctx.set_option(capi.OPT_SWEEP_TIMEOUT_MS, 3000)
+        ctx.patchmatch(2, seed=9, schedule=0)  # the context is usable again
+        np.testing.assert_array_equal(ctx.get_planes(0)[1], want[0][1])
+    finally:
+        ctx.close()
+
+
+def test_new_cost_object_withdraws_the_stored_costs(gpu_ctx, small_pair):
+    """The sweep skips a neighbour plane that is bitwise the pixel's own plane (its cost would be the stored min_cost) -- only
+    while every stored cost was computed by the CURRENT cost object.  Rebuilding the cost (census -> GRD here) on the same
+    plane field must make the sweep evaluate again, as the reference's loop would (cs_patchmatch.cc:163-216)."""
+    l, r, D = small_pair["l"], small_pair["r"], small_pair["max_dis"]
+    pc_cen = po.PlaneCost(l, r, D, 35, 5, 0.3, cc="CEN")
+    pc_grd = po.PlaneCost(l, r, D, 35, 5, 0.3)
+    pm = po.PatchMatch(l, r, D, 4)
+    kw = dict(seed=17, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_cen(D, 35, 5, 0.3)
+    pm.init(pc_cen, **kw); gpu_ctx.pm_init(seed=17)
+    pm.spatial(0, pc_cen, **kw); gpu_ctx.pm_spatial(0, seed=17)  # propagation leaves runs of bitwise identical planes
+    _assert_state_equal(gpu_ctx, pm, "census sweep")
+    gpu_ctx.build_cost_grd(D, 35, 5, 0.3)                          # same images, same plane field, another cost
+    pm.spatial(1, pc_grd, **kw); gpu_ctx.pm_spatial(1, seed=17)
+    _assert_state_equal(gpu_ctx, pm, "GRD sweep over census costs")

@@ -5,7 +5,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # the file is quoted by bench.py only while this hash matches the sources it times
 
 root, kern, out = sys.argv[1], sys.argv[2], sys.argv[3]
 desc = sys.argv[4] if len(sys.argv) > 4 else ""
@@ -26,10 +30,10 @@ per = {c: v / max(1, len(disp[c])) for c, v in sums.items()}
 gui = per["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
 dur = sum(dur_ns.values()) / len(dur_ns)
 res = {
-    "kernel": kern, "description": desc, "launches_profiled": n,
+    "kernel": kern, "description": desc, "launches_profiled": n, "kernel_source_hash": kernel_source_hash(),
     "valu_winstr_per_launch": per["SQ_INSTS_VALU"],
     "shader_cycles_per_launch_pmc": gui, "launch_ns_pmc": dur, "shader_clock_ghz": gui / dur,
-    "valu_busy_frac_pmc": per["SQ_INSTS_VALU"] * 4.1 / 1024 / gui,
+    "valu_busy_frac_pmc": per["SQ_INSTS_VALU"] * 4.0 / 1024 / gui,
     "lds_busy_frac": per["SQ_LDS_IDX_ACTIVE"] / 256 / gui,
     "lds_bank_conflict_share": per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"],
     "lds_instr_per_launch": per["SQ_INSTS_LDS"], "vmem_rd_instr_per_launch": per["SQ_INSTS_VMEM_RD"],

@@ -30,6 +30,8 @@ struct Stamp { unsigned long long clk, real; };
     int a[16];                                                                                 \
     int b = threadIdx.x * 2654435 + 17;                                                        \
     for (int k = 0; k < 16; ++k) a[k] = b + k;                                                 \
+    unsigned long long msk = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0);              \
+    asm volatile("s_mov_b64 vcc, %0" : : "s"(msk) : "vcc");                                    \
     unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();                 \
     for (int i = 0; i < n; ++i) { BLOCK128(INS) }                                              \
     unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();                 \
@@ -52,6 +54,11 @@ struct Stamp { unsigned long long clk, real; };
 #define I_MED3(k) asm volatile("v_med3_i32 %0, %0, %1, 7" : "+v"(a[k]) : "v"(b));
 #define I_LSHL(k) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[k]));
 #define I_CNDMASK(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b));
+// variants of the select, to explain the 22.7 cycles of the row above: mask in an SGPR pair written before the loop (VOP3 form);
+// VCC written once before the loop; destination different from the sources
+#define I_CNDMASK_SGPR(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "s"(msk));
+#define I_CNDMASK_VCCSET(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[k]) : "v"(b), "s"(msk));
+#define I_CNDMASK_DST(k) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[k]) : "v"(a[((k) + 5) & 15]), "v"(b));
 #define I_CMP_U32(k) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[k]), "v"(b) : "vcc");
 #define I_CMP_F64(k) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(a[(k) & 7]), "v"(b) : "vcc");
 #define I_FMA_F32(k) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[k]) : "v"(b));
@@ -75,6 +82,9 @@ KERNEL_I(k_mad_i24, I_MAD_I24)
 KERNEL_I(k_med3, I_MED3)
 KERNEL_I(k_lshl, I_LSHL)
 KERNEL_I(k_cndmask, I_CNDMASK)
+KERNEL_I(k_cndmask_sgpr, I_CNDMASK_SGPR)
+KERNEL_I(k_cndmask_vccset, I_CNDMASK_VCCSET)
+KERNEL_I(k_cndmask_dst, I_CNDMASK_DST)
 KERNEL_I(k_cmp_u32, I_CMP_U32)
 KERNEL_I(k_fma_f32, I_FMA_F32)
 KERNEL_I(k_mov_dpp, I_MOV_DPP)
@@ -93,6 +103,7 @@ int main(int argc, char **argv) {
                        {"v_fract_f64", k_fract_f64, 128}, {"v_cvt_i32_f64", k_cvt_i32_f64, 128}, {"v_cvt_f64_i32", k_cvt_f64_i32, 128},
                        {"v_cmp_lt_f64", k_cmp_f64, 128}, {"v_pk_fma_f32", k_pk_fma_f32, 128}, {"v_add_u32", k_add_u32, 128}, {"v_sad_u8", k_sad_u8, 128},
                        {"v_mad_i32_i24", k_mad_i24, 128}, {"v_med3_i32", k_med3, 128}, {"v_lshlrev_b32", k_lshl, 128}, {"v_cndmask_b32", k_cndmask, 128},
+                       {"cndmask sgpr", k_cndmask_sgpr, 128}, {"cndmask vcc set", k_cndmask_vccset, 128}, {"cndmask dst!=src", k_cndmask_dst, 128},
                        {"v_cmp_lt_u32", k_cmp_u32, 128}, {"v_fma_f32", k_fma_f32, 128}, {"v_mov_b32_dpp", k_mov_dpp, 128}};
   const int n = 2048;
   printf("%d CUs.  One workgroup of 256*w threads per CU = w co-resident waves per SIMD (w = 8: two workgroups of 1024).\n"
