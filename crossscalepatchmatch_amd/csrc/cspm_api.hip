@@ -190,7 +190,7 @@ inline unsigned row_grid(int W, int H, int views) {
 }
 inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
 inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }
-inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * (row_cap(c) + row_ocap(c)) * 16; }
+inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * wave_lds_bytes(row_cap(c), row_ocap(c)); }
 
 inline unsigned eval_grid(long long items) {
   long long nb = (items + (kEvalBlock / kWave) - 1) / (kEvalBlock / kWave);
@@ -366,6 +366,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         PixG *pxg;
         if ((rc = dalloc(c, &pxg, ppx, &c->cost_allocs))) return rc;
         L.px[v] = pxg;
+        L.px16[v] = nullptr;
         L.pc[v] = nullptr;
         L.pix[v] = img;
         L.grd[v] = nullptr;
@@ -377,8 +378,11 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         }
         if (kind == kKindGrd) {
           double *g;
-          if ((rc = dalloc(c, &g, ppx, &c->cost_allocs))) return rc;
+          if ((rc = dalloc(c, &g, ppx + 64, &c->cost_allocs))) return rc;  // + slack: a strip's last DMA piece may start inside the last row
           L.grd[v] = g;
+          uint4 *p16;
+          if ((rc = dalloc(c, &p16, ppx + 64, &c->cost_allocs))) return rc;
+          L.px16[v] = p16;
         } else if (kind == kKindImg) {
           uint8_t *gray;
           if ((rc = dalloc(c, &gray, px, &c->cost_allocs))) return rc;
@@ -870,6 +874,9 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
       hipLaunchKernelGGL(k_gradient<SrcU32>, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, SrcU32{L.pix[v], L.Wp, L.pad}, L.W, L.H,
                          L.Wp, L.pad, g);
       hipLaunchKernelGGL(k_make_aos, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)g, ppx, (PixG *)L.px[v]);
+      // image v is the other view of view 1-v: the left view (0) reads the right image at x-f, x-f-1; the right view the left image at x+f, x+f+1
+      hipLaunchKernelGGL(k_make_px16, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)g, L.Wp, L.H, v == 1 ? -1 : 1,
+                         (uint4 *)L.px16[v]);
     }
     const long long cells = (long long)L.W * L.H * (L.D + 1);
     for (int v = 0; v < 2; ++v) {

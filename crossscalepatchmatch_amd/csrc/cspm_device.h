@@ -53,6 +53,9 @@ struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
   int Wp, pad;
   const PixG *px[2];      // H rows of Wp (volume and fused-GRD sources)
+  const uint4 *px16[2];   // GRD only: image v as the OTHER view's strip slots, H rows of Wp x 16 bytes {gradient (8 B), colour, colour of
+                          // the next column towards larger disparity (x-1 in the right image, x+1 in the left image)} -- the exact
+                          // LDS image of a strip slot, so the row engine moves it global -> LDS by DMA (cspm_rows.h)
   const PixC *pc[2];      // H rows of Wp (fused-census source)
   const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
   const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only

@@ -212,6 +212,15 @@ __global__ void k_make_aos(const uint32_t *__restrict__ pix, const double *__res
   e.g = grd ? grd[i] : 0.0;
   out[i] = e;
 }
+// GRD strip slots of image v as the other view (Level::px16): {gradient, colour, colour of column x + dir}
+__global__ void k_make_px16(const uint32_t *__restrict__ pix, const double *__restrict__ grd, int Wp, int H, int dir, uint4 *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)Wp * H) return;
+  const int xp = (int)(i % Wp);
+  const int xn = min(max(xp + dir, 0), Wp - 1);
+  const double g = grd[i];
+  out[i] = uint4{(uint32_t)__double2loint(g), (uint32_t)__double2hiint(g), pix[i], pix[i - xp + xn]};
+}
 // census elements: code of the pixel (unpadded W*H x 3 words) + colour; pad cells are flagged in bit 31 of pix
 __global__ void k_make_aos_cen(const uint32_t *__restrict__ pix, const uint32_t *__restrict__ code, int W, int H, int Wp, int pad,
                                PixC *__restrict__ out) {

@@ -55,6 +55,37 @@ __host__ __device__ inline int strip_capacity(int max_dis, int half) {
   return want <= kStripRegs * kWave ? want : kStripRegs * kWave;  // wider than that: the level reads both views from global memory
 }
 __host__ __device__ inline int own_capacity(int half) { return kWave + 2 * half + 2; }
+// LDS of one wave.  One strip set = other-view slots (cap x 16 B), own-view gradients (ocap x 8 B), own-view colours (ocap x 4 B).
+// The fused-GRD path double-buffers it (the strips of window row dy+1 arrive by LDS-DMA while row dy is evaluated); the other
+// cost sources stage through registers into one set of cap + ocap 16-byte slots.
+__host__ __device__ inline int strip_set_bytes(int cap, int ocap) { return (cap * 16 + ocap * 12 + 15) / 16 * 16; }
+__host__ __device__ inline int wave_lds_bytes(int cap, int ocap) {
+  const int dbl = 2 * strip_set_bytes(cap, ocap), single = (cap + ocap) * 16;
+  return dbl > single ? dbl : single;
+}
+
+// LDS-DMA (gfx950): 64 lanes x 16 (or 4) bytes from per-lane global addresses `sbase + voff` straight into LDS at
+// [lds_dst + lane * 16 (4)) -- no VGPR carries the data, no ds_write is issued.  The compiler neither counts these loads nor
+// knows that they write LDS: the caller waits (dma_wait) before it reads what they fetched, and M0 -- the destination base,
+// compiler-reserved -- is saved and restored inside the statement (the recipe of cdna_hip_programming.md).
+__device__ __forceinline__ void dma_b128(const char *sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const char *sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// every DMA of this wave has landed and every LDS read it issued has returned (the next DMA may overwrite what they read)
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+// a wave-uniform pointer the compiler may be holding in VGPRs -> SGPR pair
+__device__ __forceinline__ const char *uniform_ptr(const char *p) {
+  const uintptr_t v = (uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char *)(((uintptr_t)hi << 32) | lo);
+}
 
 // what a lane holds of one element on its way from global memory to LDS
 template <int SRC> struct StripReg { typedef u32x3 type; };
@@ -358,7 +389,7 @@ struct RowCtx {
 };
 __device__ __forceinline__ RowCtx make_row_ctx(unsigned char *smem, int y, int cap, int ocap) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  char *base = reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * (size_t)(cap + ocap) * 16;
+  char *base = reinterpret_cast<char *>(smem + sizeof(LutMem)) + (size_t)wave * (size_t)wave_lds_bytes(cap, ocap);
   return RowCtx{
 #ifdef CSPM_ROW_STATS
       0,
@@ -426,6 +457,67 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   RowTree tree;
   const int dy_lo = max(0, A.half - cy), dy_hi = min(A.n - 1, L.H - 1 - cy + A.half);
   for (int dy = 0; dy < dy_lo; ++dy) tree.push(dy, 0.0);
+  if constexpr (SRC == kSrcGrd) {
+    if (staged) {
+      // Fused GRD cells: the strips travel global -> LDS by DMA (Level::px16 holds the other view as ready-made strip slots,
+      // Level::grd / Level::pix the own view's two arrays), double-buffered: the DMA for window row dy+1 is issued before the
+      // taps of row dy and waited for after them.  No staging registers (30 VGPRs that used to be spilled around every row), no
+      // ds_write (72 LDS-issue cycles per row), no exposed wait between fetch and commit.
+      const int set = strip_set_bytes(ctx.cap, ctx.ocap);
+      const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
+      const size_t Wp = (size_t)L.Wp;
+      const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + s_lo) * 16);
+      const char *gg = uniform_ptr(reinterpret_cast<const char *>(L.grd[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 8);
+      const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
+      const int g_dwords = 2 * o_len;
+      auto issue = [&](unsigned dst) {
+#pragma unroll
+        for (int k = 0; k < kStripRegs; ++k)
+          if (k * kWave < s_len) {
+            if (lane + k * kWave < s_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, dst + (unsigned)k * 1024u);
+          }
+#pragma unroll
+        for (int k = 0; k < 2 * kOwnRegs; ++k)
+          if (k * kWave < g_dwords) {
+            if (lane + k * kWave < g_dwords) dma_b32(gg, (unsigned)(lane + k * kWave) * 4u, dst + (unsigned)(ctx.cap * 16 + k * 256));
+          }
+#pragma unroll
+        for (int k = 0; k < kOwnRegs; ++k)
+          if (k * kWave < o_len) {
+            if (lane + k * kWave < o_len) dma_b32(gp, (unsigned)(lane + k * kWave) * 4u, dst + (unsigned)(ctx.cap * 16 + ctx.ocap * 8 + k * 256));
+          }
+        g16 += Wp * 16; gg += Wp * 8; gp += Wp * 4;  // the next image row
+      };
+      dma_wait();  // the previous level's strip reads have returned
+      issue(lds0);
+      int par = 0;
+      for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+        const int qy = cy - A.half + dy;
+        dma_wait();  // row dy has landed; the reads of row dy-1 (the buffer the next DMA overwrites) have returned
+        if (dy < dy_hi) issue(lds0 + (unsigned)(par ? 0 : set));
+        RowSrc Rr = R;
+        const int boff = par ? set : 0;
+        Rr.adr_o += boff; Rr.adr_g += boff; Rr.adr_g2 += boff; Rr.adr_g3 += boff; Rr.adr_p += boff; Rr.img_base += boff;
+        const double rowterm = b * (double)qy + c;  // q_disp_y, :155
+        double Rsum;
+        if (!edge) {
+          // see the register-staged loop below for the all-valid test
+          const int jl = (A.n - 1) % kRowMod;
+          const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+          const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+          const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+          const bool safe = (L.D >= 2) & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+          Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? row_taps<SRC, VIEW, false, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
+                                                            : row_taps<SRC, VIEW, false, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+        } else {
+          Rsum = row_taps<SRC, VIEW, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+        }
+        tree.push(dy, Rsum);
+        par ^= 1;
+      }
+      return tree.total(dy_hi + 1);
+    }
+  }
   // The strips of window row dy+1 are fetched into registers while row dy is being evaluated and written to LDS afterwards:
   // the LDS queue of a wave is in order, so one buffer per strip suffices (reads of row dy precede the writes of row dy+1).
   // (Measured alternatives: a second other-view buffer written mid-row, so that the staging registers die early -- slower,
