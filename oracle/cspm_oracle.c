@@ -732,6 +732,26 @@ double csor_pc_cost_thresh(const csor_pc *pc, int ref_x, int ref_y, const double
   return cost;
 }
 
+/* the per-level sums of PreCSPC::GetPlaneCost (pre_cs_pc.cc:142-186) before they are weighted: level_out[s] = scale_cost of
+ * level s (study tool: tools/lb_exit_study.py).  Returns the number of levels. */
+int csor_pc_level_costs(const csor_pc *pc, int ref_x, int ref_y, const double norm[3], const double param[3], int view,
+                        int sum_order, double *level_out) {
+  if (!pc->cs) {
+    level_cost(pc, view, 0, ref_x, ref_y, param[0], param[1], param[2], sum_order, 0.0, 1.0, K_DOUBLE_MAX, 0, NULL, &level_out[0]);
+    return 1;
+  }
+  double cur_disp = param[0] * ref_x + param[1] * ref_y + param[2];
+  int cur_y = ref_y, cur_x = ref_x;
+  for (int s = 0; s < pc->scale_num; ++s) {
+    const double pt[3] = {(double)cur_x, (double)cur_y, cur_disp};
+    double prm[3];
+    csor_plane_param(norm, pt, prm);
+    level_cost(pc, view, s, cur_x, cur_y, prm[0], prm[1], prm[2], sum_order, 0.0, 1.0, K_DOUBLE_MAX, 0, NULL, &level_out[s]);
+    cur_y /= 2; cur_x /= 2; cur_disp /= 2.0;
+  }
+  return pc->scale_num;
+}
+
 double csor_pc_cost(const csor_pc *pc, int x, int y, const double norm[3], const double param[3], int view, int sum_order) {
   return csor_pc_cost_thresh(pc, x, y, norm, param, view, sum_order, K_DOUBLE_MAX, NULL);
 }

@@ -111,6 +111,9 @@ double   csor_pc_cost(const csor_pc *pc, int x, int y, const double norm[3], con
 double   csor_pc_cost_thresh(const csor_pc *pc, int x, int y, const double norm[3],
                              const double param[3], int view, int sum_order, double thresh,
                              long long *taps);
+/* unweighted per-level sums of one evaluation (a study hook, tools/lb_exit_study.py); returns the number of levels */
+int      csor_pc_level_costs(const csor_pc *pc, int x, int y, const double norm[3], const double param[3], int view,
+                             int sum_order, double *level_out);
 /* exact number of in-image window taps of one evaluation at (x,y) */
 long long csor_pc_taps(const csor_pc *pc, int x, int y);
 

@@ -73,6 +73,7 @@ def lib():
         "csor_pc_cost_thresh": (C.c_double, [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, C.c_double,
                                              C.POINTER(C.c_longlong)]),
         "csor_pc_taps": (C.c_longlong, [C.c_void_p, C.c_int, C.c_int]),
+        "csor_pc_level_costs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, dp]),
         "csor_pm_create": (C.c_void_p, [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
         "csor_pm_destroy": (None, [C.c_void_p]),
         "csor_pm_run": (None, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(PmOpts)]),
@@ -170,6 +171,13 @@ class PlaneCost:
         c = self.L.csor_pc_cost_thresh(self.p, int(x), int(y), _dp(n), _dp(p), int(view), int(sum_order),
                                        float(thresh), C.byref(taps))
         return c, taps.value
+
+    def level_costs(self, x, y, norm, param, view, sum_order=SUM_SERIAL):
+        n = np.ascontiguousarray(norm, dtype=np.float64)
+        p = np.ascontiguousarray(param, dtype=np.float64)
+        o = np.zeros(self.levels)
+        self.L.csor_pc_level_costs(self.p, int(x), int(y), _dp(n), _dp(p), int(view), int(sum_order), _dp(o))
+        return o
 
     def taps(self, x, y):
         return self.L.csor_pc_taps(self.p, int(x), int(y))
