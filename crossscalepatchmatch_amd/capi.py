@@ -28,7 +28,7 @@ SYMBOLS = [
     "cspm_pm_default_params", "cspm_patchmatch", "cspm_pm_init", "cspm_pm_spatial", "cspm_pm_view", "cspm_pm_refine",
     "cspm_get_planes", "cspm_set_planes", "cspm_get_disparity_u8", "cspm_get_disparity_f64",
     "cspm_disparity_u8_device", "cspm_postprocess", "cspm_postprocess_device", "cspm_enable_timing", "cspm_reset_timing", "cspm_get_timing",
-    "cspm_taps_per_view_pass", "cspm_row_engine_taps_per_view_pass",
+    "cspm_taps_per_view_pass", "cspm_row_engine_taps_per_view_pass", "cspm_fpm_begin", "cspm_fpm_candidates", "cspm_fpm_commit",
 ]
 
 
@@ -111,6 +111,9 @@ def load_library():
         "cspm_enable_timing": (C.c_int, [vp, C.c_int]),
         "cspm_reset_timing": (C.c_int, [vp]),
         "cspm_get_timing": (C.c_int, [vp, C.c_int, llp, dp, llp]),
+        "cspm_fpm_begin": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "cspm_fpm_candidates": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, pp, ip, ip, ip, dp]),
+        "cspm_fpm_commit": (C.c_int, [vp, dp]),
         "cspm_taps_per_view_pass": (C.c_longlong, [vp]),
         "cspm_row_engine_taps_per_view_pass": (C.c_longlong, [vp]),
     }

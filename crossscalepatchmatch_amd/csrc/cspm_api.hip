@@ -103,6 +103,12 @@ struct cspm_ctx {
   int last_iters = 0;
   cspm_pm_params last_params{};
   long long sweep_fallbacks = 0;      // how often that happened (cspm_get_option)
+  // CSPatchMatch over a foreign IPlaneCost (cspm_fpm_*): candidate buffers and what the pending batch was
+  FpmCand fpm{nullptr, nullptr, nullptr, nullptr};
+  long long fpm_cap = 0;
+  int fpm_phase = -1, fpm_iter = 0, fpm_step = 0, fpm_inc = 1;
+  long long fpm_count = 0;
+  cspm_pm_params fpm_params{};
   // timing
   bool timing = false;
   std::vector<TimingRec> recs;
@@ -219,6 +225,13 @@ void free_field(cspm_ctx *c) {
     c->d_dis[v] = nullptr;
     c->d_valid[v] = nullptr;
   }
+  if (c->fpm.xy) (void)hipFree(c->fpm.xy);
+  if (c->fpm.view) (void)hipFree(c->fpm.view);
+  if (c->fpm.plane) (void)hipFree(c->fpm.plane);
+  if (c->fpm.cost) (void)hipFree(c->fpm.cost);
+  c->fpm = FpmCand{nullptr, nullptr, nullptr, nullptr};
+  c->fpm_cap = 0;
+  c->fpm_phase = -1;
   if (c->d_sweep_ctrl) (void)hipFree(c->d_sweep_ctrl);
   if (c->d_sweep_gran) (void)hipFree(c->d_sweep_gran);
   if (c->d_sweep_start) (void)hipFree(c->d_sweep_start);
@@ -1430,6 +1443,112 @@ int cspm_debug_alive(unsigned long long *out16, int reset) {
   return CSPM_OK;
 }
 #endif
+
+// ---- CSPatchMatch over a foreign IPlaneCost: see cspm_foreign.h -----------------------------------------------------------
+int cspm_fpm_begin(cspm_ctx *c, int w, int h, int max_dis) {
+  if (!c) return CSPM_ERR_ARG;
+  if (w < 1 || h < 1 || max_dis < 1) return fail(c, CSPM_ERR_ARG, "bad w / h / max_dis");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  if (w != c->W || h != c->H) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_cost(c);
+    free_field(c);
+    free_images(c);
+    c->W = w; c->H = h;
+  }
+  c->max_dis = max_dis;
+  c->field_consistent = false;
+  c->phases_unchecked = true;
+  int rc = ensure_field(c);
+  if (rc) return rc;
+  const long long need = 2LL * w * h;
+  if (c->fpm_cap < need) {
+    if ((rc = dalloc(c, &c->fpm.xy, (size_t)need * 2, nullptr)) || (rc = dalloc(c, &c->fpm.view, (size_t)need, nullptr)) ||
+        (rc = dalloc(c, &c->fpm.plane, (size_t)need * 6, nullptr)) || (rc = dalloc(c, &c->fpm.cost, (size_t)need, nullptr)))
+      return rc;
+    c->fpm_cap = need;
+  }
+  c->fpm_phase = -1;
+  return CSPM_OK;
+}
+
+int cspm_fpm_candidates(cspm_ctx *c, int phase, int iter, int step, const cspm_pm_params *p, int *n_out, int *xy_out, int *view_out,
+                        double *plane_out) {
+  if (!c || !n_out || !xy_out || !view_out || !plane_out) return CSPM_ERR_ARG;
+  if (!c->fpm_cap) return fail(c, CSPM_ERR_STATE, "cspm_fpm_begin first");
+  if (!p) p = &kDefaultParams;
+  if (p->schedule != CSPM_SCHED_RASTER) return fail(c, CSPM_ERR_ARG, "a foreign IPlaneCost runs the reference's raster schedule only");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  Pm pm = make_pm(c, p);
+  const long long n = (long long)c->W * c->H;
+  long long count = 0;
+  int inc = 1;
+  switch (phase) {
+    case CSPM_FPM_INIT:
+    case CSPM_FPM_REFINE: {
+      double z = c->max_dis / 2.0, nn = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145; halved once per step (:342-343)
+      for (int k = 0; k < step; ++k) { z /= 2.0; nn /= 2.0; }
+      if (phase == CSPM_FPM_REFINE && (step < 0 || z < 0.1)) return fail(c, CSPM_ERR_ARG, "refinement step out of range");
+      count = 2 * n;
+      hipLaunchKernelGGL(k_fpm_point_cand, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, phase == CSPM_FPM_REFINE ? 1 : 0, iter, step, z, nn);
+      break;
+    }
+    case CSPM_FPM_VIEW:
+      if (step < 0 || step > 1) return fail(c, CSPM_ERR_ARG, "view propagation: step = target view, 0 or 1");
+      count = n;
+      hipLaunchKernelGGL(k_fpm_view_cand, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, step);
+      break;
+    case CSPM_FPM_SPATIAL: {
+      if (step < 0 || step > c->W + c->H - 2) return fail(c, CSPM_ERR_ARG, "spatial propagation: step = anti-diagonal, 0 .. w+h-2");
+      inc = (iter % 2 == 0) ? 1 : -1;
+      const int cnt = std::min(c->H - 1, step) - std::max(0, step - (c->W - 1)) + 1;
+      count = 4LL * cnt;
+      hipLaunchKernelGGL(k_fpm_diag_cand, dim3(ew_grid(2LL * cnt)), dim3(256), 0, c->stream, pm, c->fpm, step, inc);
+      break;
+    }
+    default: return fail(c, CSPM_ERR_ARG, "unknown phase");
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(xy_out, c->fpm.xy, sizeof(int) * 2 * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(view_out, c->fpm.view, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(plane_out, c->fpm.plane, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->fpm_phase = phase; c->fpm_iter = iter; c->fpm_step = step; c->fpm_inc = inc; c->fpm_count = count; c->fpm_params = *p;
+  *n_out = (int)count;
+  return CSPM_OK;
+}
+
+int cspm_fpm_commit(cspm_ctx *c, const double *cost) {
+  if (!c || !cost) return CSPM_ERR_ARG;
+  if (c->fpm_phase < 0) return fail(c, CSPM_ERR_STATE, "no candidate batch pending (cspm_fpm_candidates)");
+  DevGuard guard_(c->device);
+  if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
+  Pm pm = make_pm(c, &c->fpm_params);
+  const long long count = c->fpm_count;
+  HIPCHK(c, hipMemcpyAsync(c->fpm.cost, cost, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  switch (c->fpm_phase) {
+    case CSPM_FPM_INIT:
+    case CSPM_FPM_REFINE:
+      hipLaunchKernelGGL(k_fpm_point_commit, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, c->fpm_phase == CSPM_FPM_REFINE ? 1 : 0);
+      break;
+    case CSPM_FPM_VIEW: {
+      const size_t shmem = (size_t)c->W * (sizeof(unsigned long long) + sizeof(unsigned int));
+      if (shmem > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the view-propagation row resolver");
+      hipLaunchKernelGGL(k_fpm_view_commit, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, c->vc);
+      hipLaunchKernelGGL(k_view_resolve, dim3(c->H), dim3(256), shmem, c->stream, pm, c->fpm_step, c->fpm_iter % 2 == 0 ? 0 : 1, c->vc);
+      break;
+    }
+    case CSPM_FPM_SPATIAL:
+      hipLaunchKernelGGL(k_fpm_diag_commit, dim3(ew_grid(count / 2)), dim3(256), 0, c->stream, pm, c->fpm, c->fpm_step, c->fpm_inc);
+      break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // `cost` is the caller's buffer
+  c->fpm_phase = -1;
+  return CSPM_OK;
+}
 
 #ifdef CSPM_ROW_STATS
 // debug build only (tools/row_stats.py): the row-engine statistics of cspm_rows.h g_rowstat

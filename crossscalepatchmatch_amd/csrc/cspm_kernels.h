@@ -25,6 +25,7 @@
 #include "cspm_chain.h"
 #include "cspm_rows.h"
 #include "cspm_tap.h"
+#include "cspm_foreign.h"
 
 #pragma clang fp contract(off)
 

@@ -9,9 +9,11 @@
 class CSPatchMatch {
  public:
   CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_dis, const int &dis_scale);
-  ~CSPatchMatch() {}
+  ~CSPatchMatch();
   // init, iter_num x (spatial, view, refinement), PlaneToDisp, optional PostProcessing (cs_patchmatch.cc:51-109).
-  // plane_cost must be a device cost (PreSSPC / PreCSPC): the loop runs on its GPU.
+  // A device cost (PreSSPC / PreCSPC / GrdPC / CSPC of this host layer) runs the whole loop on its GPU.  Any other IPlaneCost
+  // (a plugin: i_plane_cost.h:28-33) is priced through its GetPlaneCost, candidate batch by candidate batch, while the plane
+  // field, the random streams and the accept rules stay on the device (PatchMatchForeign).
   void PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp);
   Mat &dis(const RefView &view) { return dis_[view]; }
 
@@ -31,4 +33,7 @@ class CSPatchMatch {
   uint64_t seed_;
   int schedule_, rb_rounds_;
   cspm_ctx *last_ctx_;
+  cspm_ctx *own_ctx_;  // foreign IPlaneCost: the context that holds the plane field
+  void PatchMatchForeign(int iter_num, const IPlaneCost *plane_cost, bool use_pp);
+  CSPatchMatch(const CSPatchMatch &);
 };

@@ -59,6 +59,11 @@ cspm_ctx *DevicePlaneCost::kept_ctx_ = NULL;
 int DevicePlaneCost::kept_device_ = -1;
 std::vector<cspm_ctx *> DevicePlaneCost::live_;
 
+void DevicePlaneCost::adopt(cspm_ctx *ctx) { live_.push_back(ctx); }
+void DevicePlaneCost::disown(cspm_ctx *ctx) {
+  for (size_t i = 0; i < live_.size(); ++i)
+    if (live_[i] == ctx) { live_.erase(live_.begin() + i); return; }
+}
 bool DevicePlaneCost::is_live(const cspm_ctx *ctx) {
   for (size_t i = 0; i < live_.size(); ++i)
     if (live_[i] == ctx) return true;
@@ -162,7 +167,7 @@ double DevicePlaneCost::GetPlaneCost(const int &ref_x, const int &ref_y, const P
 
 // ---------------------------------------------------------------- CSPatchMatch (cs_patchmatch.cc:3-109)
 CSPatchMatch::CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_dis, const int &dis_scale)
-    : max_dis_(max_dis), dis_scale_(dis_scale), seed_(12345), schedule_(CSPM_SCHED_RASTER), rb_rounds_(1), last_ctx_(NULL) {
+    : max_dis_(max_dis), dis_scale_(dis_scale), seed_(12345), schedule_(CSPM_SCHED_RASTER), rb_rounds_(1), last_ctx_(NULL), own_ctx_(NULL) {
   CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // cs_patchmatch.cc:8
   img_[kLeft] = l_img.clone();
   img_[kRight] = r_img.clone();
@@ -171,11 +176,74 @@ CSPatchMatch::CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_di
   for (int v = 0; v < kViewNum; ++v) dis_[v] = Mat::zeros(hei_, wid_, CV_8UC1);
 }
 
+// A foreign IPlaneCost (i_plane_cost.h:28-33): the device owns the plane field, the random streams and the accept rules
+// (cspm_fpm_*, csrc/cspm_foreign.h); every candidate is priced by the plugin's GetPlaneCost, exactly the calls the reference
+// makes (cs_patchmatch.cc:144,181,191,200,208,269,334), batch by batch.  GetPlaneCost is const and re-entrant
+// (the reference calls it from OpenMP threads): the batches are evaluated in parallel when this file is built with -fopenmp.
+void CSPatchMatch::PatchMatchForeign(int iter_num, const IPlaneCost *plane_cost, bool use_pp) {
+  if (!own_ctx_) {
+    check(cspm_create(&own_ctx_, DevicePlaneCost::device), NULL, "cspm_create");
+    DevicePlaneCost::adopt(own_ctx_);
+  }
+  cspm_ctx *ctx = own_ctx_;
+  const Mat l = img_[kLeft].clone(), r = img_[kRight].clone();
+  check(cspm_set_images(ctx, l.data, r.data, l.cols, l.rows, l.step), ctx, "cspm_set_images");
+  check(cspm_fpm_begin(ctx, wid_, hei_, max_dis_), ctx, "cspm_fpm_begin");
+  cspm_pm_params p;
+  cspm_pm_default_params(&p);
+  p.seed = seed_;
+  if (schedule_ != CSPM_SCHED_RASTER) throw std::runtime_error("CSPatchMatch: a foreign IPlaneCost runs the raster schedule only");
+  const size_t cap = (size_t)2 * wid_ * hei_;
+  std::vector<int> xy(2 * cap), view(cap);
+  std::vector<double> plane(6 * cap), cost(cap);
+  auto batch = [&](int phase, int iter, int step) {
+    int n = 0;
+    check(cspm_fpm_candidates(ctx, phase, iter, step, &p, &n, xy.data(), view.data(), plane.data()), ctx, "cspm_fpm_candidates");
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+    for (int i = 0; i < n; ++i) {
+      cost[i] = 0.0;
+      if (xy[2 * i] < 0) continue;  // no such candidate (first sweep row / column, proposal outside the image)
+      const double *q = &plane[6 * (size_t)i];
+      Plane pl;
+      pl.set_norm(Point3d(q[0], q[1], q[2]));
+      pl.set_param(Vec3d(q[3], q[4], q[5]));
+      cost[i] = plane_cost->GetPlaneCost(xy[2 * i], xy[2 * i + 1], pl, view[i] == 0 ? kLeft : kRight);
+    }
+    check(cspm_fpm_commit(ctx, cost.data()), ctx, "cspm_fpm_commit");
+  };
+  int steps = 0;
+  for (double z = max_dis_ / 2.0; z >= 0.1; z /= 2.0) ++steps;  // kZStopThres_ (cs_patchmatch.h:146), :299-301,342
+  batch(CSPM_FPM_INIT, 0, 0);                                   // cs_patchmatch.cc:55
+  for (int it = 0; it < iter_num; ++it) {                       // :65-102
+    for (int k = 1; k <= wid_ + hei_ - 2; ++k) batch(CSPM_FPM_SPATIAL, it, k);
+    for (int v = 0; v < kViewNum; ++v) batch(CSPM_FPM_VIEW, it, v);
+    for (int st = 0; st < steps; ++st) batch(CSPM_FPM_REFINE, it, st);
+  }
+  if (use_pp) {  // PostProcessing reads the level-0 images of a cost object: the cheapest one provides them
+    check(cspm_build_cost_img(ctx, max_dis_, 35, 0, 0.0), ctx, "cspm_build_cost_img");
+    check(cspm_postprocess(ctx, dis_scale_, dis_[kLeft].data, dis_[kRight].data, dis_[kLeft].step), ctx, "cspm_postprocess");
+  } else {
+    for (int v = 0; v < kViewNum; ++v)
+      check(cspm_get_disparity_u8(ctx, v, dis_scale_, dis_[v].data, dis_[v].step), ctx, "cspm_get_disparity_u8");
+  }
+  last_ctx_ = ctx;
+}
+
+CSPatchMatch::~CSPatchMatch() {
+  if (own_ctx_) {
+    DevicePlaneCost::disown(own_ctx_);
+    cspm_destroy(own_ctx_);
+  }
+}
+
 void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp) {
   const IDevicePlaneCost *dev = dynamic_cast<const IDevicePlaneCost *>(plane_cost);
-  if (!dev)
-    throw std::runtime_error("CSPatchMatch::PatchMatch: the plane cost is not device-resident. This build runs PatchMatch on the "
-                             "GPU only; wrap a foreign cost function as a CCMethod (PreSSPC/PreCSPC upload its volumes).");
+  if (!dev) {
+    PatchMatchForeign(iter_num, plane_cost, use_pp);
+    return;
+  }
   cspm_ctx *ctx = dev->device_ctx();
   cspm_pm_params p;
   cspm_pm_default_params(&p);

@@ -22,6 +22,8 @@ class DevicePlaneCost : public IPlaneCost, public IDevicePlaneCost {
   // is this context still owned by a live (or parked) DevicePlaneCost?  CSPatchMatch borrows the context of the cost object it
   // ran on (planes(), disparity()) and must not touch it once that object is gone
   static bool is_live(const cspm_ctx *ctx);
+  static void adopt(cspm_ctx *ctx);   // a context owned by someone else (CSPatchMatch's own, for a foreign IPlaneCost) joins / leaves
+  static void disown(cspm_ctx *ctx);  // the registry
 
  private:
   DevicePlaneCost(const DevicePlaneCost &);

@@ -158,6 +158,30 @@ int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_ou
  * PatchMatch(iter_num, plane_cost, use_pp = true) without leaving the device (cs_patchmatch.cc:103-107) */
 int cspm_postprocess_device(cspm_ctx *ctx, int dis_scale, void *d_l_out, void *d_r_out);
 
+/* ---- CSPatchMatch::PatchMatch over a FOREIGN IPlaneCost (plane_cost/i_plane_cost.h:28-33) ------------------------------
+ * Any object with a GetPlaneCost(x, y, plane, view) that is not one of this library's device costs: the reference drives it
+ * through the virtual call (call sites cs_patchmatch.cc:144,181,191,200,208,269,334).  Here the device keeps the plane field,
+ * draws every candidate from the same random streams and applies the reference's accept rules; the CALLER evaluates the
+ * candidates with its cost function -- the plugin contract, batched:
+ *     cspm_fpm_begin(ctx, w, h, max_dis);                       plane field, no cost object, no images needed
+ *     per batch:  cspm_fpm_candidates(...) -> n candidates {xy, view, plane};  cost[i] = GetPlaneCost(...) for xy[2i] >= 0;
+ *                 cspm_fpm_commit(ctx, cost)
+ *   phase CSPM_FPM_INIT    (iter, step ignored): InitRandomPlane, 2*w*h candidates                (:115-148)
+ *   phase CSPM_FPM_SPATIAL (step = anti-diagonal 0 .. w+h-2 of the raster sweep of iteration iter): 2 per pixel, x- then
+ *                           y-predecessor's plane, xy[2i] = -1 where the pixel has no such predecessor (:163-216)
+ *   phase CSPM_FPM_VIEW    (step = target view): w*h candidates, one per source pixel of the other view (:229-277)
+ *   phase CSPM_FPM_REFINE  (step = halving step 0 ..): 2*w*h candidates                            (:292-345)
+ * Arrays must hold 2*w*h candidates.  Synchronous.  Afterwards cspm_get_planes / cspm_get_disparity_* / cspm_postprocess
+ * (which needs cspm_set_images for the weighted median) read the result as usual. */
+#define CSPM_FPM_INIT 0
+#define CSPM_FPM_SPATIAL 1
+#define CSPM_FPM_VIEW 2
+#define CSPM_FPM_REFINE 3
+int cspm_fpm_begin(cspm_ctx *ctx, int w, int h, int max_dis);
+int cspm_fpm_candidates(cspm_ctx *ctx, int phase, int iter, int step, const cspm_pm_params *p, int *n_out, int *xy_out, int *view_out,
+                        double *plane_out);
+int cspm_fpm_commit(cspm_ctx *ctx, const double *cost);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by hipEvents on the ctx stream. */
 #define CSPM_K_GRD 0      /* cost-volume construction kernels */
