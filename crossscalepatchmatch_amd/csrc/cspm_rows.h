@@ -37,6 +37,9 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_INIT_MINW
 #define CSPM_INIT_MINW CSPM_ROW_MINW
 #endif
+#ifndef CSPM_CELL_MODE
+#define CSPM_CELL_MODE 1  // coarse levels of the fused GRD cost: per-row cell and weight tables (cell mode below); 0 = always the general taps
+#endif
 constexpr int kRowBlock = kRowWaves * kWave;
 #ifdef CSPM_ROW_STATS
 // debug (tools/row_stats.py): per phase slot (0 init, 1 view, 2+step refinement), pyramid level and bucket, the number of staged
@@ -116,6 +119,7 @@ __device__ __forceinline__ T lds_ld(int adr) {
   typedef typename LdsVec<T>::type V;
   const V v = *(__attribute__((address_space(3))) const V *)(uintptr_t)(unsigned)adr;
   if constexpr (sizeof(T) == 16) return T{v[0], v[1], v[2], v[3]};
+  else if constexpr (__is_floating_point(T)) return v;
   else if constexpr (sizeof(T) == 8) return T{v[0], v[1]};
   else return v;
 }
@@ -376,6 +380,81 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
   return Rsum;
 }
 
+// ------------------------------------------------------------------------------------------------
+// CELL MODE (coarse pyramid levels of the fused GRD cost).  At level s the 64 lanes of a wave share 64 >> s distinct centres,
+// the window row they walk has only (64 >> s) + 2*half distinct columns, and the level has few disparities: the wave touches
+// NQ x D distinct cells and ncent x n distinct guide weights on a window row, against 64 x n x 2 cell evaluations and 64 x n
+// weight look-ups when every lane works for itself.  So the wave first builds, per window row,
+//   cells[d][q]  = myCostGrd(own column q, other column q -+ d), d = 1 .. D           (the SAME grd_cell(): same bits)
+//   wgts[c][j]   = exp(-|I_centre(c) - I(c + j)| / 10), 0 for a column outside the image (the same table)
+// in LDS and then walks the window: a tap is its disparity, two 8-byte cell reads, one weight read, the interpolation and the
+// accumulation -- 8 VALU instructions and 6 LDS cycles instead of 23 and 21.  Same terms, same order: identical results.
+// Used where it fits the wave's LDS (levels 3 and 4 of a KITTI pyramid); measured in DESIGN.md section 7.
+// ------------------------------------------------------------------------------------------------
+struct CellRow {
+  int adr_c;   // lane: LDS address of cells[d = 0][q0] of the lane's window column 0 (biased one disparity down: f indexes d = f)
+  int stride;  // bytes between consecutive disparities: NQ * 8
+  int adr_w;   // lane: LDS address of wgts[centre of the lane][0]
+  int adr_w2, adr_w3, adr_w4;  // == adr_w, opaque to the compiler: the weight reads of a batch must not be merged into ds_read2_b64 (half rate)
+};
+template <bool ALLV, int J0, int J1>
+__device__ __forceinline__ void cell_batch(const RowLevel &A, const CellRow &C, int adr_c, int adr_c1, int adr_w, int g8, double pa, double Gg,
+                                           double S[kRowMod]) {
+  constexpr int N = J1 - J0;
+  double c0[N], c1[N], w[N], fr[N];
+  bool valid[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int j = J0 + k;
+    const double q_disp = tap_disp(pa, (double)j, Gg);
+    const DispSplit d = ALLV ? split_disp_valid(q_disp) : split_disp(q_disp, A.Dm1, A.has_valid);
+    fr[k] = d.fr;
+    valid[k] = d.valid;
+    int a0, a1;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a0) : "v"(d.f), "s"(C.stride), "v"(adr_c));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(d.f), "s"(C.stride), "v"(adr_c1));
+    c0[k] = lds_ld<double>(a0 + j * 8);
+    c1[k] = lds_ld<double>(a1 + j * 8);
+    w[k] = lds_ld<double>((k == 0 ? adr_w : k == 1 ? C.adr_w2 : k == 2 ? C.adr_w3 : C.adr_w4) + g8 + j * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double tmp = lerp_cells(fr[k], c0[k], c1[k]);
+    const double maxc = A.maxc;
+    const double t = (ALLV || valid[k]) ? tmp : maxc;
+    S[J0 + k] = __builtin_fma(w[k], t, S[J0 + k]);
+  }
+}
+template <bool ALLV, int CNT>
+__device__ __forceinline__ void cell_group(const RowLevel &A, const CellRow &C, int g0, double pa, double rowterm, double &qxg_d, double S[kRowMod]) {
+  const double Gg = group_disp(pa, qxg_d, rowterm);
+  qxg_d += (double)kRowMod;
+  const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w;
+  constexpr int SUB = 4;
+  cell_batch<ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, C, adr_c, adr_c1, adr_w, g8, pa, Gg, S);
+  if constexpr (CNT > SUB) cell_batch<ALLV, SUB, CNT>(A, C, adr_c, adr_c1, adr_w, g8, pa, Gg, S);
+}
+template <bool ALLV>
+__device__ __forceinline__ double cell_row_taps(const RowLevel &A, const CellRow &C, double pa, double rowterm, double qx0_d) {
+  double S[kRowMod];
+#pragma unroll
+  for (int j = 0; j < kRowMod; ++j) S[j] = 0.0;
+  double qx_d = qx0_d;
+  const int full = A.n / kRowMod * kRowMod;
+  int g0 = 0;
+  for (; g0 < full; g0 += kRowMod) cell_group<ALLV, kRowMod>(A, C, g0, pa, rowterm, qx_d, S);
+  switch (A.n - full) {
+#define CSPM_TAIL(K) case K: cell_group<ALLV, K>(A, C, g0, pa, rowterm, qx_d, S); break;
+    CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
+#undef CSPM_TAIL
+    default: break;
+  }
+  double Rsum = S[0];
+#pragma unroll
+  for (int j = 1; j < kRowMod; ++j) Rsum = Rsum + S[j];
+  return Rsum;
+}
+
 // Per-wave description of the 64 evaluation centres of one pass (wave-uniform unless noted)
 struct RowCtx {
 #ifdef CSPM_ROW_STATS
@@ -457,6 +536,129 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   RowTree tree;
   const int dy_lo = max(0, A.half - cy), dy_hi = min(A.n - 1, L.H - 1 - cy + A.half);
   for (int dy = 0; dy < dy_lo; ++dy) tree.push(dy, 0.0);
+  if constexpr (SRC == kSrcGrd) {
+    // cell mode: does the row's cell table + weight table + ONE compact strip set fit this wave's LDS?
+    const int ncent = cmax - cmin + 1, NQ = o_len;
+    const int off_g = (s_len * 16 + 15) / 16 * 16, off_p = off_g + NQ * 8, off_c = (off_p + NQ * 4 + 15) / 16 * 16;
+    const int off_w = off_c + NQ * D * 8, off_i = off_w + ncent * A.n * 8, cell_bytes = off_i + ncent * 4;
+    if (CSPM_CELL_MODE && staged && D >= 2 && cell_bytes + 64 <= wave_lds_bytes(ctx.cap, ctx.ocap)) {
+      const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
+      const size_t Wp = (size_t)L.Wp;
+      const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + s_lo) * 16);
+      const char *gg = uniform_ptr(reinterpret_cast<const char *>(L.grd[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 8);
+      const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
+      const int g_dwords = 2 * NQ;
+      auto issue = [&]() {  // one compact strip set at lds0: slots | gradients | colours
+#pragma unroll
+        for (int k = 0; k < kStripRegs; ++k)
+          if (k * kWave < s_len) {
+            if (lane + k * kWave < s_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, lds0 + (unsigned)k * 1024u);
+          }
+#pragma unroll
+        for (int k = 0; k < 2 * kOwnRegs; ++k)
+          if (k * kWave < g_dwords) {
+            if (lane + k * kWave < g_dwords) dma_b32(gg, (unsigned)(lane + k * kWave) * 4u, lds0 + (unsigned)(off_g + k * 256));
+          }
+#pragma unroll
+        for (int k = 0; k < kOwnRegs; ++k)
+          if (k * kWave < NQ) {
+            if (lane + k * kWave < NQ) dma_b32(gp, (unsigned)(lane + k * kWave) * 4u, lds0 + (unsigned)(off_p + k * 256));
+          }
+        g16 += Wp * 16; gg += Wp * 8; gp += Wp * 4;
+      };
+      dma_wait();  // the previous level's LDS reads have returned
+      issue();
+      // the centres' colours (window centre row cy, fixed for the level): lanes with the same centre write the same word
+      const int ipc_a = strip_a + off_i;
+      *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)(ipc_a + (cx - cmin) * 4) = Ip;
+      CellRow C;
+      C.stride = NQ * 8;
+      C.adr_c = strip_a + off_c + (cx - cmin) * 8 - C.stride;  // cells[d][q] holds disparity d + 1: f indexes row f - 1
+      C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
+      C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
+      asm volatile("" : "+v"(C.adr_w2));
+      asm volatile("" : "+v"(C.adr_w3));
+      asm volatile("" : "+v"(C.adr_w4));
+      const int gcol0 = cmin - A.half;  // image column of table column q = 0
+      for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+        const int qy = cy - A.half + dy;
+        dma_wait();  // the strips of row dy have landed; the taps of row dy-1 have read their tables
+        // ---- cells[d][q], d = 0 .. D-1 for disparities 1 .. D: lane = table column q (its own element is read once), disparities in
+        // batches of four (an entry is a chain of three dependent LDS round trips; the batch overlaps them).  The other view's slot
+        // moves one slot per disparity and the table one row: every address in the batch is an immediate off two running bases.
+        for (int q0 = 0; q0 < NQ; q0 += kWave) {  // one trip unless the row has more than 64 columns
+          const int q = q0 + lane;
+          const bool qon = q < NQ;
+          const int qs = qon ? q : 0;
+          const uint2 gq2 = lds_ld<uint2>(strip_a + off_g + qs * 8);
+          const uint32_t pq = lds_ld<uint32_t>(strip_a + off_p + qs * 4);
+          const double gq = __hiloint2double((int)gq2.y, (int)gq2.x);
+          int adr_s = strip_a + (VIEW == 0 ? qs - 1 + D : qs + 1) * 16;  // slot of disparity 1
+          int adr_t = strip_a + off_c + qs * 8;                            // cells[0][q]
+          constexpr int U = 4;
+          for (int d0 = 0; d0 < D; d0 += U) {
+            uint4 o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u] = lds_ld<uint4>(adr_s + (VIEW == 0 ? -16 : 16) * u);  // d0 + u < D + U: the strip set has the room
+            double cell[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cell[u] = grd_cell(lut.a, pq, gq, o[u].z, __hiloint2double((int)o[u].y, (int)o[u].x));
+            int at = adr_t;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (qon && d0 + u < D) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)at = cell[u];
+              at += C.stride;
+            }
+            adr_s += (VIEW == 0 ? -16 : 16) * U;
+            adr_t = at;
+          }
+        }
+        // ---- wgts[c][j]: lane = window column j, one centre per trip (its colour is one broadcast read)
+        for (int j0 = 0; j0 < A.n; j0 += kWave) {
+          const int j = j0 + lane;
+          const bool jon = j < A.n;
+          const int js = jon ? j : 0;
+          int adr_p = strip_a + off_p + js * 4, adr_o = strip_a + off_w + js * 8;
+          int col = gcol0 + js;
+          constexpr int U = 4;
+          for (int c0 = 0; c0 < ncent; c0 += U) {
+            uint32_t ic[U], pq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              ic[u] = lds_ld<uint32_t>(ipc_a + (c0 + u) * 4);  // c0 + u < ncent + U: inside the wave's LDS, the value is not used beyond ncent
+              pq[u] = lds_ld<uint32_t>(adr_p + u * 4);
+            }
+            double w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              int sad = (int)__builtin_amdgcn_sad_u8(ic[u], pq[u], 0u);
+              sad = ((unsigned)(col + u) < (unsigned)A.W) ? sad : kLutZero;  // outside the image: weight 0, the tap adds +0.0
+              w[u] = lut.w[sad];
+            }
+            int ao = adr_o;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (jon && c0 + u < ncent) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)ao = w[u];
+              ao += A.n * 8;
+            }
+            adr_p += U * 4; adr_o = ao; col += U;
+          }
+        }
+        dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go
+        if (dy < dy_hi) issue();
+        const double rowterm = b * (double)qy + c;  // q_disp_y, :155
+        const int jl = (A.n - 1) % kRowMod;
+        const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+        const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+        const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+        const bool safe = (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+        const double Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? cell_row_taps<true>(A, C, a, rowterm, qx0_d)
+                                                                       : cell_row_taps<false>(A, C, a, rowterm, qx0_d);
+        tree.push(dy, Rsum);
+      }
+      return tree.total(dy_hi + 1);
+    }
+  }
   if constexpr (SRC == kSrcGrd) {
     if (staged) {
       // Fused GRD cells: the strips travel global -> LDS by DMA (Level::px16 holds the other view as ready-made strip slots,
