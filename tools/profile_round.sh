@@ -19,6 +19,11 @@ cd $R
 tools/pmc_run.sh $TAG refine,sweep,view_eval,init -- python $R/bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/pmc_to_json.py gpurun_out/$TAG k_refine gpurun_out/$TAG/refine_pmc.json "bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline: C3, (1 warm-up + 1 timed) pairs x 3 iterations = 6 launches of k_refine<true,1>" > /dev/null
 python tools/pmc_to_json.py gpurun_out/$TAG k_spatial_sweep gpurun_out/$TAG/sweep_pmc.json "same command: 6 launches of k_spatial_sweep<true,1>" > /dev/null
+# 5. the other BASELINE.json configs (3 pairs in flight; C5 includes post-processing; C4 goes through batch.run_batch) -- for reference, not the headline
+for C in C1 C2 C4 C5; do
+  S=6; [ $C = C5 ] && S=3
+  python bench.py --config $C --no-cpu-baseline --steps $S --warmup 2 > $O/bench_$(echo $C | tr A-Z a-z).json 2> /dev/null
+done
 ./tools/ubench/valu_issue > $O/valu_issue.txt 2>&1
 python tools/bench_brief.py default < $O/bench_default.json
 python tools/bench_brief.py inflight1 < $O/bench_inflight1.json
