@@ -61,7 +61,7 @@ def cpu_baseline_on(name, device_index=0):
     import crossscalepatchmatch_amd as cs
     from crossscalepatchmatch_amd import synth
     cfg, l, r, _, _ = synth.make_config(name)
-    threads = max(1, min(os.cpu_count() or 1, cfg["h"]))
+    threads = max(1, min(po.effective_cpus(), cfg["h"]))  # the cores this process may use (cgroup quota), not the visible count
     t0 = time.perf_counter()
     pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
     pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])

@@ -821,8 +821,16 @@ static inline uint64_t pix_key(const csor_pm *pm, const csor_pm_opts *o, int x, 
  * normalises (:137-140), i.e. a uniformly distributed direction; cv::RNG's ziggurat is not
  * reproducible on a GPU bit for bit, so both sides draw the direction by rejection sampling in
  * the unit ball (no transcendental functions) -- same distribution, see DESIGN.md "RNG". */
+static void apply_threads(const csor_pm_opts *o) {
+#ifdef _OPENMP
+  if (o->threads > 0) omp_set_num_threads(o->threads);
+#else
+  (void)o;
+#endif
+}
 void csor_pm_init(csor_pm *pm, const csor_pc *pc, const csor_pm_opts *o) {
   if (!o) o = &k_default_opts;
+  apply_threads(o);
   for (int v = 0; v < 2; ++v) {
     const uint32_t sid = csor_stream_id(0, 0, 0, v);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -928,6 +936,7 @@ static void spatial_redblack(csor_pm *pm, int cur_iter, const csor_pc *pc, const
 }
 
 void csor_pm_spatial(csor_pm *pm, int cur_iter, const csor_pc *pc, const csor_pm_opts *o) {
+  apply_threads(o ? o : &k_default_opts);
   if (!o) o = &k_default_opts;
   if (o->schedule == CSOR_SCHED_REDBLACK) spatial_redblack(pm, cur_iter, pc, o);
   else spatial_raster(pm, cur_iter, pc, o);
@@ -969,6 +978,7 @@ void csor_pm_view(csor_pm *pm, int cur_iter, const csor_pc *pc, const csor_pm_op
 /* cs_patchmatch.cc:292-345  PlaneRefinement(max_dis/2.0, kMaxNorm_, kZStopThres_) */
 void csor_pm_refine(csor_pm *pm, int cur_iter, const csor_pc *pc, const csor_pm_opts *o) {
   if (!o) o = &k_default_opts;
+  apply_threads(o);
   double z_iter = pm->max_dis / 2.0, n_iter = K_MAX_NORM;
   int step = 0;
   while (z_iter >= K_Z_STOP) {
