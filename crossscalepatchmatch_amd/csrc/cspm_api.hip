@@ -574,19 +574,30 @@ int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
   return ensure_field(c);
 }
 
+// A launch gets 64 KB of dynamic LDS without asking; a wide disparity range (max_dis > ~290: two strip sets of 384 slots per wave)
+// needs a little more -- gfx950 has 160 KB per CU -- and a kernel has to opt in once per instantiation.
+template <class K>
+inline void allow_lds(K kern, size_t shmem) {
+  if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
+#define LAUNCH_ONE(K, grid, block, shmem, ...)                                \
+  do {                                                                       \
+    allow_lds(K, shmem);                                                     \
+    hipLaunchKernelGGL(K, grid, block, shmem, c->stream, __VA_ARGS__);       \
+  } while (0)
 #define LAUNCH_CS(kern, grid, block, shmem, ...)                                                                  \
   do {                                                                                                            \
     const int src_ = c->cost.fused;                                                                               \
     if (c->cost.cs) {                                                                                             \
-      if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<true, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);          \
-      else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<true, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);     \
-      else if (src_ == kSrcImg) hipLaunchKernelGGL((kern<true, kSrcImg>), grid, block, shmem, c->stream, __VA_ARGS__);     \
-      else hipLaunchKernelGGL((kern<true, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                       \
+      if (src_ == kSrcGrd) LAUNCH_ONE((kern<true, kSrcGrd>), grid, block, shmem, __VA_ARGS__);                    \
+      else if (src_ == kSrcCen) LAUNCH_ONE((kern<true, kSrcCen>), grid, block, shmem, __VA_ARGS__);               \
+      else if (src_ == kSrcImg) LAUNCH_ONE((kern<true, kSrcImg>), grid, block, shmem, __VA_ARGS__);               \
+      else LAUNCH_ONE((kern<true, kSrcVolume>), grid, block, shmem, __VA_ARGS__);                                 \
     } else {                                                                                                      \
-      if (src_ == kSrcGrd) hipLaunchKernelGGL((kern<false, kSrcGrd>), grid, block, shmem, c->stream, __VA_ARGS__);         \
-      else if (src_ == kSrcCen) hipLaunchKernelGGL((kern<false, kSrcCen>), grid, block, shmem, c->stream, __VA_ARGS__);    \
-      else if (src_ == kSrcImg) hipLaunchKernelGGL((kern<false, kSrcImg>), grid, block, shmem, c->stream, __VA_ARGS__);    \
-      else hipLaunchKernelGGL((kern<false, kSrcVolume>), grid, block, shmem, c->stream, __VA_ARGS__);                      \
+      if (src_ == kSrcGrd) LAUNCH_ONE((kern<false, kSrcGrd>), grid, block, shmem, __VA_ARGS__);                   \
+      else if (src_ == kSrcCen) LAUNCH_ONE((kern<false, kSrcCen>), grid, block, shmem, __VA_ARGS__);              \
+      else if (src_ == kSrcImg) LAUNCH_ONE((kern<false, kSrcImg>), grid, block, shmem, __VA_ARGS__);              \
+      else LAUNCH_ONE((kern<false, kSrcVolume>), grid, block, shmem, __VA_ARGS__);                                \
     }                                                                                                             \
   } while (0)
 

@@ -366,3 +366,19 @@ def test_new_cost_object_withdraws_the_stored_costs(gpu_ctx, small_pair):
     gpu_ctx.build_cost_grd(D, 35, 5, 0.3)                          # same images, same plane field, another cost
     pm.spatial(1, pc_grd, **kw); gpu_ctx.pm_spatial(1, seed=17)
     _assert_state_equal(gpu_ctx, pm, "GRD sweep over census costs")
+
+
+def test_wide_disparity_range(gpu_ctx):
+    """max_dis = 300: the level-0 strips would be wider than the 384 slots a wave stages (that level reads global memory), the
+    other levels stage 2 x 384-slot strip sets per wave and the row kernels need more than the 64 KB of dynamic LDS a launch gets
+    without opting in.  Whole pipeline == the oracle."""
+    from crossscalepatchmatch_amd import synth
+    w, h, D = 420, 20, 300
+    l, r, _, _ = synth.make_pair(w, h, D, regions=3, seed=77)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(D, 35, 5, 0.3)
+    pc = po.PlaneCost(l, r, D, 35, 5, 0.3)
+    pm = po.PatchMatch(l, r, D, 1)
+    pm.run(1, pc, False, seed=8, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    gpu_ctx.patchmatch(1, seed=8, schedule=0)
+    _assert_state_equal(gpu_ctx, pm, "max_dis 300")
