@@ -41,14 +41,19 @@ PMC_FILE = os.path.join(ROOT, "profiles", "refine_pmc.json")  # SQ_INSTS_VALU et
 
 
 def kernel_source_hash():
-    """sha256 over the device sources: a committed PMC file is only quoted while it describes the kernels that are being timed"""
+    """sha256 over the device sources with comments and white space removed: a committed PMC file is only quoted while it
+    describes the CODE of the kernels that are being timed (editing a comment does not invalidate a measurement)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "crossscalepatchmatch_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")):
+            src = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)     # block comments
+            src = re.sub(r"//[^\n]*", " ", src)                   # line comments (no string literal in csrc/ contains "//")
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(" ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -10,8 +10,9 @@
 //
 // Cell costs come from one of three sources, selected at compile time:
 //   SRC = kSrcGrd: GRD cell cost computed on the fly from the padded images + gradients (bit-identical
-//                  to reading GrdCC's volume, cc/grd_cc.cpp:4-35,60-154); nothing but ~12 B/pixel per
-//                  view and level is ever read, so the working set stays in L2 / Infinity Cache.
+//                  to reading the device-cell volume: myCostGrd of cc/grd_cc.cpp:4-35 with its last multiply-add
+//                  contracted, cspm_tap.h); nothing but ~40 B/pixel per view and level is ever read, so the
+//                  working set stays in L2 / Infinity Cache.
 //   SRC = kSrcCen: census / Hamming cell cost computed on the fly from 80-bit codes (cc/cen_cc.cc:47-66).
 //   SRC = kSrcVolume: cost volumes in HBM (any CCMethod plugin; what the reference's PreSSPC/PreCSPC do).
 #pragma once

@@ -9,11 +9,16 @@
 //   * both views' rows are staged once per window row into wave-private LDS strips (other view: [cx_min-half-D, cx_max+half]
 //     for the left view; own view: [cx_min-half, cx_max+half]): every tap of every lane reads its operands from the strips
 //     with one address computation, however incoherent the 64 planes are (random initialisation, early refinement steps);
-//     the global loads that fill the strips are coalesced row runs, one window row ahead of the taps;
+//     the strips are coalesced row runs that arrive one window row ahead of the taps -- by LDS-DMA into the other of two
+//     strip sets for the fused GRD cost, through registers for the other cost sources;
 //   * rows and columns outside the image cost nothing (rows are skipped by scalar control flow; only waves that touch
-//     the image border carry the per-tap column mask);
-//   * the running sums are registers of the lane: no cross-lane reduction, no per-level table set-up.
-// Per tap and lane: 33.3 VALU instructions (19 of them f64) and 7 LDS reads, no global load.
+//     the image border carry the per-tap column mask); rows on which every lane interpolates (nearly all once the planes have
+//     settled) run without clamp, validity test and select;
+//   * the running sums are registers of the lane: no cross-lane reduction, no per-level table set-up;
+//   * on the coarse pyramid levels, where the 64 lanes share a few centres and columns, the wave builds per-row tables of cells
+//     and guide weights once and the taps read those (cell mode).
+// Per tap and lane: 23.3 VALU instructions in an all-valid row, 27.4 in a general row, ~10 in cell mode, and 6.3 LDS reads
+// (DESIGN.md section 5.1), no global load.
 #pragma once
 #include "cspm_tap.h"
 
@@ -26,10 +31,11 @@ namespace cspm {
 #endif
 constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share the two lookup tables)
 #ifndef CSPM_ROW_MINW
-#define CSPM_ROW_MINW 3                       // waves per SIMD the register allocator must leave room for: 168 VGPRs.  Measured
-                                              // (C3, ms per k_refine launch): 2 waves 66.1 (211 VGPRs, no spill), 3 waves 55.7,
-                                              // 4 waves 58.3 (128 VGPRs), 5 waves 64.3, 6 waves 67.2; workgroups of 2/3/4/6/8/12
-                                              // waves at 3 per SIMD: 56.0 / 58.4 / 55.7 / 78.9 / - / 63.4
+#define CSPM_ROW_MINW 3                       // waves per SIMD the register allocator must leave room for: 168 VGPRs (157 used, no
+                                              // scratch).  Measured in round 2 (C3, ms per k_refine launch): 2 waves 66.1, 3 waves
+                                              // 55.7, 4 waves 58.3 (128 VGPRs), 5 waves 64.3, 6 waves 67.2; round 3: 4 waves per SIMD
+                                              // (one 16-wave workgroup per CU, 128 VGPRs, 104 B scratch) 45.1 against 38.5;
+                                              // workgroups of 2/3/4 waves at 3 per SIMD are equal, larger ones slower
 #endif
 #ifndef CSPM_VIEW_MINW
 #define CSPM_VIEW_MINW CSPM_ROW_MINW

@@ -127,8 +127,9 @@ int cspm_cen_build_cv_host(int device, const double *l_rgb, const double *r_rgb,
 
 /* ---- IPlaneCost::GetPlaneCost, batched (plane_cost/i_plane_cost.h:28-33) ----------------------
  * xy: 2 ints per item; plane: 6 doubles per item = Plane::norm() then Plane::param().
- * Summation order is the device order ("ROWTREE7": the same terms as the reference's
- * serial sum, other association; differs by rounding only, <= 1e-12 relative). */
+ * The cost is computed in the DEVICE ORDER: the same terms as the reference's serial sum in the
+ * "ROWTREE7" association, with five multiply-adds per tap contracted into fmas (disparity, the last step of a GRD cell x2,
+ * interpolation, accumulation); differs from the reference's SSE2 arithmetic by rounding only, <= 1e-12 relative. */
 int cspm_plane_cost_batch(cspm_ctx *ctx, int view, int n, const int *xy, const double *norm_param, double *cost_out);
 
 /* ---- CSPatchMatch ------------------------------------------------------------------------------
