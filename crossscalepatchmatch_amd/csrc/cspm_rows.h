@@ -545,7 +545,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   if constexpr (SRC == kSrcGrd) {
     // cell mode: does the row's cell table + weight table + ONE compact strip set fit this wave's LDS?
     const int ncent = cmax - cmin + 1, NQ = o_len;
-    const int off_g = (s_len * 16 + 15) / 16 * 16, off_p = off_g + NQ * 8, off_c = (off_p + NQ * 4 + 15) / 16 * 16;
+    const int off_g = s_len * 16, off_p = off_g + (NQ * 8 + 15) / 16 * 16, off_c = off_p + (NQ * 4 + 15) / 16 * 16;  // 16-byte DMA pieces
     const int off_w = off_c + NQ * D * 8, off_i = off_w + ncent * A.n * 8, cell_bytes = off_i + ncent * 4;
     if (CSPM_CELL_MODE && staged && D >= 2 && cell_bytes + 64 <= wave_lds_bytes(ctx.cap, ctx.ocap)) {
       const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
@@ -553,23 +553,15 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + s_lo) * 16);
       const char *gg = uniform_ptr(reinterpret_cast<const char *>(L.grd[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 8);
       const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
-      const int g_dwords = 2 * NQ;
+      const int g_p16 = (NQ * 8 + 15) / 16, p_p16 = (NQ * 4 + 15) / 16;  // 16-byte pieces of the own view's gradient / colour runs
       auto issue = [&]() {  // one compact strip set at lds0: slots | gradients | colours
 #pragma unroll
         for (int k = 0; k < kStripRegs; ++k)
           if (k * kWave < s_len) {
             if (lane + k * kWave < s_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, lds0 + (unsigned)k * 1024u);
           }
-#pragma unroll
-        for (int k = 0; k < 2 * kOwnRegs; ++k)
-          if (k * kWave < g_dwords) {
-            if (lane + k * kWave < g_dwords) dma_b32(gg, (unsigned)(lane + k * kWave) * 4u, lds0 + (unsigned)(off_g + k * 256));
-          }
-#pragma unroll
-        for (int k = 0; k < kOwnRegs; ++k)
-          if (k * kWave < NQ) {
-            if (lane + k * kWave < NQ) dma_b32(gp, (unsigned)(lane + k * kWave) * 4u, lds0 + (unsigned)(off_p + k * 256));
-          }
+        if (lane < g_p16) dma_b128(gg, (unsigned)lane * 16u, lds0 + (unsigned)off_g);  // <= 64 pieces: the run has <= 128 columns
+        if (lane < p_p16) dma_b128(gp, (unsigned)lane * 16u, lds0 + (unsigned)off_p);
         g16 += Wp * 16; gg += Wp * 8; gp += Wp * 4;
       };
       dma_wait();  // the previous level's LDS reads have returned
@@ -677,23 +669,17 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + s_lo) * 16);
       const char *gg = uniform_ptr(reinterpret_cast<const char *>(L.grd[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 8);
       const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
-      const int g_dwords = 2 * o_len;
+      // the own view's gradient and colour runs as 16-byte pieces (one DMA each; a piece may run up to 8 / 12 bytes past the run:
+      // inside the padded rows in memory, inside the array's capacity -- ocap is even -- or the set's rounding in LDS)
+      const int g_p16 = (o_len * 8 + 15) / 16, p_p16 = (o_len * 4 + 15) / 16;
       auto issue = [&](unsigned dst) {
 #pragma unroll
         for (int k = 0; k < kStripRegs; ++k)
           if (k * kWave < s_len) {
             if (lane + k * kWave < s_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, dst + (unsigned)k * 1024u);
           }
-#pragma unroll
-        for (int k = 0; k < 2 * kOwnRegs; ++k)
-          if (k * kWave < g_dwords) {
-            if (lane + k * kWave < g_dwords) dma_b32(gg, (unsigned)(lane + k * kWave) * 4u, dst + (unsigned)(ctx.cap * 16 + k * 256));
-          }
-#pragma unroll
-        for (int k = 0; k < kOwnRegs; ++k)
-          if (k * kWave < o_len) {
-            if (lane + k * kWave < o_len) dma_b32(gp, (unsigned)(lane + k * kWave) * 4u, dst + (unsigned)(ctx.cap * 16 + ctx.ocap * 8 + k * 256));
-          }
+        if (lane < g_p16) dma_b128(gg, (unsigned)lane * 16u, dst + (unsigned)(ctx.cap * 16));
+        if (lane < p_p16) dma_b128(gp, (unsigned)lane * 16u, dst + (unsigned)(ctx.cap * 16 + ctx.ocap * 8));
         g16 += Wp * 16; gg += Wp * 8; gp += Wp * 4;  // the next image row
       };
       dma_wait();  // the previous level's strip reads have returned
