@@ -64,3 +64,29 @@ def test_bench_fails_loudly_without_a_gpu():
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"] + extra, capture_output=True, timeout=600)
         assert p.returncode != 0
         assert b"needs a GPU" in p.stderr + p.stdout
+
+
+def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path, monkeypatch):
+    """bench.py quotes the committed rocprofv3 counters (profiles/refine_pmc.json) only while kernel_source_hash() equals the hash
+    the file was stamped with: editing a comment must not invalidate a measurement, editing code must."""
+    import bench
+    d = tmp_path / "crossscalepatchmatch_amd" / "csrc"
+    d.mkdir(parents=True)
+    (d / "a.h").write_text("// header\nint f(int x) { return x + 1; }  /* plus one */\n")
+    (d / "b.hip").write_text("__global__ void k() {}\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h0 = bench.kernel_source_hash()
+    (d / "a.h").write_text("// another header comment\n\nint f(int x) {\n  return x + 1;   /* still plus one */\n}\n")
+    assert bench.kernel_source_hash() == h0
+    (d / "a.h").write_text("// header\nint f(int x) { return x + 2; }\n")
+    assert bench.kernel_source_hash() != h0
+
+
+def test_effective_cpus_is_bounded_by_what_the_container_may_use():
+    from oracle import pyoracle as po
+    n = po.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        assert n <= len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
