@@ -88,7 +88,8 @@ struct cspm_ctx {
   Field f[2]{};
   ViewCand vc{nullptr, nullptr, nullptr};
   uint8_t *d_dis[2] = {nullptr, nullptr};
-  int *d_valid[2] = {nullptr, nullptr};
+  uint8_t *d_valid[2] = {nullptr, nullptr};  // post-processing: left-right consistency flags
+  unsigned int *d_todo = nullptr;            // post-processing: per view n indices of inconsistent pixels, then the two counts
   // persistent raster sweep (k_spatial_sweep)
   unsigned int *d_sweep_ctrl = nullptr, *d_sweep_start = nullptr;
   unsigned long long *d_sweep_gran = nullptr;  // persistent sweep: 12 data-tagged granules per pixel and view (cspm_chain.h)
@@ -225,6 +226,8 @@ void free_field(cspm_ctx *c) {
     c->d_dis[v] = nullptr;
     c->d_valid[v] = nullptr;
   }
+  if (c->d_todo) (void)hipFree(c->d_todo);
+  c->d_todo = nullptr;
   if (c->fpm.xy) (void)hipFree(c->fpm.xy);
   if (c->fpm.view) (void)hipFree(c->fpm.view);
   if (c->fpm.plane) (void)hipFree(c->fpm.plane);
@@ -491,6 +494,7 @@ int ensure_field(cspm_ctx *c) {
     if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
   }
+  if ((rc = dalloc(c, &c->d_todo, 2 * n + 2, nullptr))) return rc;
   // persistent sweep state: control words, per-pixel granules (tag zero = never written), diagonal start table
   if ((rc = dalloc(c, &c->d_sweep_ctrl, 2, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
@@ -1339,13 +1343,18 @@ static int postprocess_enqueue(cspm_ctx *c, int dis_scale) {
   Timed t(c, CSPM_K_POST, 0);
   for (int v = 0; v < 2; ++v)  // PlaneToDisp (cs_patchmatch.cc:103)
     hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_dis[v], (size_t)c->W);
-  for (int v = 0; v < 2; ++v)  // LeftRightCheck (:516)
-    hipLaunchKernelGGL(k_lr_check, dim3(ew_grid(n)), dim3(256), 0, c->stream, c->d_dis[v], c->d_dis[1 - v], c->W, c->H, v, dis_scale, c->d_valid[v]);
-  for (int v = 0; v < 2; ++v)  // FillInvalid (:545)
-    hipLaunchKernelGGL(k_fill_invalid, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_valid[v], c->d_dis[v]);
-  for (int v = 0; v < 2; ++v)  // WeightedMedian(valid, 35, WMF_GAMMA) (:571-573); exp(-i/10) is the plane-cost LUT
-    hipLaunchKernelGGL(k_weighted_median, dim3(ew_grid(n, 64)), dim3(64), 0, c->stream, L0.pix[v], L0.Wp, L0.pad, c->W, c->H,
-                       c->d_valid[v], c->d_lut, c->d_dis[v], 35 / 2);
+  unsigned int *todo_cnt = c->d_todo + 2 * (size_t)n;
+  HIPCHK(c, hipMemsetAsync(todo_cnt, 0, 2 * sizeof(unsigned int), c->stream));
+  // LeftRightCheck of both views (:516) on the maps as PlaneToDisp left them
+  hipLaunchKernelGGL(k_lr_check, dim3(ew_grid(2 * n)), dim3(256), 0, c->stream, c->d_dis[0], c->d_dis[1], c->W, c->H, dis_scale, c->d_valid[0],
+                     c->d_valid[1]);
+  // FillInvalid (:545): a workgroup per row and view
+  if (fill_rows_shmem(c->W) > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the row scan of FillInvalid");
+  LAUNCH_ONE(k_fill_rows, dim3(2u * (unsigned)c->H), dim3(kFillBlock), fill_rows_shmem(c->W), pm, dis_scale, c->d_valid[0], c->d_valid[1], c->d_dis[0],
+             c->d_dis[1], c->d_todo, todo_cnt);
+  // WeightedMedian(valid, 35, WMF_GAMMA) (:571-573): a wavefront per listed pixel; exp(-i/10) is the plane-cost LUT
+  hipLaunchKernelGGL(k_weighted_median, dim3((unsigned)c->ncu * 8u), dim3(kMedianBlock), 0, c->stream, L0.pix[0], L0.pix[1], L0.Wp, L0.pad, c->W,
+                     c->H, c->d_valid[0], c->d_valid[1], c->d_lut, c->d_dis[0], c->d_dis[1], c->d_todo, todo_cnt, 35 / 2);
   HIPCHK(c, hipGetLastError());
   return CSPM_OK;
 }

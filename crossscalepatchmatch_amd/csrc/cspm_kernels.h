@@ -103,24 +103,31 @@ __global__ void k_plane_to_disp_f64(Pm pm, int v, double *__restrict__ out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// CSPatchMatch::PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps.  Deterministic integer /
-// f64 work, < 1 % of a run: one thread per pixel, loops exactly in the reference's order so that the
-// weighted-median histogram sums round identically.
+// CSPatchMatch::PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps, both views per launch.
+//   k_lr_check          one lane per pixel and view: the consistency flag
+//   k_fill_rows         one workgroup per image row and view: nearest consistent pixel on either side by a two-level scan
+//                       (lane-private runs, then the 256 run summaries), inconsistent pixels get the smaller of the two
+//                       planes' disparities and are appended to the view's work list
+//   k_weighted_median   one WAVEFRONT per listed pixel: the 35 columns of a window row sit in 35 lanes, the 256-bin histogram
+//                       in 4 registers of each lane (bin = 64*k + lane), the additions are replayed in window order so every
+//                       bin and the running total round as the reference's scalar loop does
 // ------------------------------------------------------------------------------------------------
-// LeftRightCheck (:347-369)
-__global__ void k_lr_check(const uint8_t *__restrict__ dis, const uint8_t *__restrict__ other, int W, int H, int v, int dis_scale,
-                           int *__restrict__ valid) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)W * H) return;
+// LeftRightCheck (:347-369): a pixel is consistent when the other view, at the column its rounded disparity points to,
+// holds a disparity within half a pixel, and its own disparity is positive
+__global__ void k_lr_check(const uint8_t *__restrict__ dis0, const uint8_t *__restrict__ dis1, int W, int H, int dis_scale,
+                           uint8_t *__restrict__ ok0, uint8_t *__restrict__ ok1) {
+  const long long n = (long long)W * H;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  const int v = i >= n ? 1 : 0;
+  i -= v * n;
+  const uint8_t *mine = v ? dis1 : dis0, *theirs = v ? dis0 : dis1;
   const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  int ok = 0;
-  const double cur_dis = dis[i] * 1.0 / dis_scale;
-  const int other_x = x + (2 * v - 1) * round2int(cur_dis);
-  if (other_x >= 0 && other_x < W) {
-    const double other_dis = other[(size_t)y * W + other_x] * 1.0 / dis_scale;
-    if (fabs(cur_dis - other_dis) <= 0.5 && cur_dis > 0.0) ok = 1;
-  }
-  valid[i] = ok;
+  const double d = mine[i] * 1.0 / dis_scale;
+  const int ox = x + (2 * v - 1) * round2int(d);
+  bool ok = false;
+  if (ox >= 0 && ox < W) ok = fabs(d - theirs[(size_t)y * W + ox] * 1.0 / dis_scale) <= 0.5 && d > 0.0;
+  (v ? ok1 : ok0)[i] = ok ? 1 : 0;
 }
 
 __device__ __forceinline__ uint8_t sat_u8(int q) { return (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); }
@@ -131,62 +138,162 @@ __device__ __forceinline__ double plane_disp_at(const Field &f, long long j, int
   return d;
 }
 
-// FillInvalid (:370-428): nearest valid pixel to the left / right on the row, their planes evaluated at x
-__global__ void k_fill_invalid(Pm pm, int v, int dis_scale, const int *__restrict__ valid, uint8_t *__restrict__ dis) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)pm.W * pm.H) return;
-  if (valid[i]) return;
-  const int y = (int)(i / pm.W), x = (int)(i - (long long)y * pm.W);
-  const long long row = (long long)y * pm.W;
-  int l_first = x, r_first = x;
-  while (l_first >= 0 && !valid[row + l_first]) --l_first;
-  while (r_first < pm.W && !valid[row + r_first]) ++r_first;
-  const bool l_find = l_first >= 0, r_find = r_first < pm.W;
+constexpr int kFillBlock = 256;
+// dynamic LDS of k_fill_rows for an image of width W: flags, nearest-left table, run summaries
+inline size_t fill_rows_shmem(int W) { return (size_t)((W + 3) & ~3) + sizeof(int) * ((size_t)W + 2 * kFillBlock + 1); }
+
+// FillInvalid (:370-428).  Grid = 2*H workgroups (view-major).  todo[v*n ...] receives the row-major indices of the view's
+// inconsistent pixels (rows in no particular order: the median treats them independently), todo_cnt[v] their number.
+__global__ __launch_bounds__(kFillBlock) void k_fill_rows(Pm pm, int dis_scale, const uint8_t *__restrict__ ok0, const uint8_t *__restrict__ ok1,
+                                                          uint8_t *__restrict__ dis0, uint8_t *__restrict__ dis1,
+                                                          unsigned int *__restrict__ todo, unsigned int *__restrict__ todo_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fill_smem[];
+  const int W = pm.W, H = pm.H, t = (int)threadIdx.x;
+  const int v = (int)blockIdx.x / H, y = (int)blockIdx.x - v * H;
+  const long long row = (long long)y * W, n = (long long)W * H;
+  uint8_t *flag = fill_smem;
+  int *near_l = reinterpret_cast<int *>(fill_smem + ((W + 3) & ~3));
+  int *run_l = near_l + W, *run_r = run_l + kFillBlock, *list_base = run_r + kFillBlock;
+  const uint8_t *ok = (v ? ok1 : ok0) + row;
+  uint8_t *dis = (v ? dis1 : dis0) + row;
+  for (int x = t; x < W; x += kFillBlock) flag[x] = ok[x];  // coalesced
+  __syncthreads();
+  // lane-private run [x0, x1): last consistent column in it, first consistent column in it, number of inconsistent ones
+  const int per = (W + kFillBlock - 1) / kFillBlock, x0 = min(W, t * per), x1 = min(W, x0 + per);
+  int last = -1, first = W, holes = 0;
+  for (int x = x0; x < x1; ++x) {
+    if (flag[x]) { last = x; if (first == W) first = x; }
+    else ++holes;
+  }
+  run_l[t] = last;
+  run_r[t] = first;
+  __syncthreads();
+  // inclusive max-scan of the run summaries towards the right, min-scan towards the left (Hillis-Steele over 256 entries)
+  for (int step = 1; step < kFillBlock; step <<= 1) {
+    const int a = t >= step ? run_l[t - step] : -1, b = t + step < kFillBlock ? run_r[t + step] : W;
+    __syncthreads();
+    run_l[t] = max(run_l[t], a);
+    run_r[t] = min(run_r[t], b);
+    __syncthreads();
+  }
+  int carry = t > 0 ? run_l[t - 1] : -1;
+  const int carry_r = t + 1 < kFillBlock ? run_r[t + 1] : W;
+  for (int x = x0; x < x1; ++x) {
+    if (flag[x]) carry = x;
+    near_l[x] = carry;
+  }
+  __syncthreads();
+  // where this run's inconsistent pixels go in the view's work list: exclusive sum of `holes`, one reservation per row
+  run_l[t] = holes;
+  __syncthreads();
+  for (int step = 1; step < kFillBlock; step <<= 1) {
+    const int a = t >= step ? run_l[t - step] : 0;
+    __syncthreads();
+    run_l[t] += a;
+    __syncthreads();
+  }
+  if (t == kFillBlock - 1) *list_base = (int)atomicAdd(&todo_cnt[v], (unsigned int)run_l[t]);
+  __syncthreads();
+  unsigned int *out = todo + (size_t)v * n + (unsigned int)*list_base + (unsigned int)(run_l[t] - holes);
   const Field &f = pm.f[v];
-  if (l_find && r_find) {
-    const double l_d = plane_disp_at(f, row + l_first, x, y), r_d = plane_disp_at(f, row + r_first, x, y);
-    dis[i] = sat_u8(dis_scale * round2int(l_d <= r_d ? l_d : r_d));
-  } else if (l_find) {
-    dis[i] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + l_first, x, y)));
-  } else if (r_find) {
-    dis[i] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + r_first, x, y)));
+  carry = carry_r;
+  for (int x = x1 - 1; x >= x0; --x) {
+    if (flag[x]) { carry = x; continue; }
+    const int l = near_l[x], r = carry;
+    if (l >= 0 && r < W) {
+      const double dl = plane_disp_at(f, row + l, x, y), dr = plane_disp_at(f, row + r, x, y);
+      dis[x] = sat_u8(dis_scale * round2int(dl <= dr ? dl : dr));
+    } else if (l >= 0) {
+      dis[x] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + l, x, y)));
+    } else if (r < W) {
+      dis[x] = sat_u8(dis_scale * round2int(plane_disp_at(f, row + r, x, y)));
+    }
+    *out++ = (unsigned int)(row + x);
   }
 }
 
-// WeightedMedian(valid, 35, WMF_GAMMA) (:430-506): invalid pixels only, valid neighbours only
-__global__ __launch_bounds__(64) void k_weighted_median(const uint32_t *__restrict__ pix, int Wp, int pad, int W, int H,
-                                                        const int *__restrict__ valid, const double *__restrict__ lut,
-                                                        uint8_t *__restrict__ dis, int half_wnd) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)W * H) return;
-  if (valid[i]) return;
-  const int y = (int)(i / W), x = (int)(i - (long long)y * W);
-  double disp_hist[256];
-  for (int d = 0; d < 256; ++d) disp_hist[d] = 0.0;
-  const uint32_t p = pix[(size_t)y * Wp + pad + x];
-  double sum_wgt = 0.0;
-  for (int wy = -half_wnd; wy <= half_wnd; ++wy) {
-    const int qy = y + wy;
-    if (qy < 0 || qy >= H) continue;
-    for (int wx = -half_wnd; wx <= half_wnd; ++wx) {
-      const int qx = x + wx;
-      if (qx < 0 || qx >= W) continue;
-      const size_t q = (size_t)qy * W + qx;
-      if (!valid[q]) continue;
-      const int clr_diff = (int)__builtin_amdgcn_sad_u8(p, pix[(size_t)qy * Wp + pad + qx], 0u);
-      const double wgt = lut[clr_diff];
-      disp_hist[dis[q]] += wgt;
-      sum_wgt += wgt;
+__device__ __forceinline__ double lane_value(double v, int src_lane) {  // src_lane wave-uniform
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)u, src_lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(u >> 32), src_lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+constexpr int kMedianBlock = 256;
+constexpr int kMedianRows = 6;  // window rows whose loads are in flight together
+// WeightedMedian(valid, 35, WMF_GAMMA) (:430-506): inconsistent pixels only, consistent neighbours only.  2*half_wnd+1 <= 64.
+// The 256 bins live in the wave's 2 KB of LDS; one lane replays the additions in window order (same-bin additions are a
+// dependent chain whatever the layout, and so is the running total), the other lanes' work is the gather that feeds it.
+__global__ __launch_bounds__(kMedianBlock) void k_weighted_median(const uint32_t *__restrict__ pix0, const uint32_t *__restrict__ pix1, int Wp, int pad,
+                                                                  int W, int H, const uint8_t *__restrict__ ok0, const uint8_t *__restrict__ ok1,
+                                                                  const double *__restrict__ lut, uint8_t *__restrict__ dis0, uint8_t *__restrict__ dis1,
+                                                                  const unsigned int *__restrict__ todo, const unsigned int *__restrict__ todo_cnt,
+                                                                  int half_wnd) {
+  __shared__ double s_hist[kMedianBlock / kWave][256];
+  const int lane = (int)(threadIdx.x & 63);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double *hist = s_hist[wave_in_block];
+  const unsigned int wave = blockIdx.x * (kMedianBlock / kWave) + (unsigned int)wave_in_block;
+  const unsigned int nwaves = gridDim.x * (kMedianBlock / kWave);
+  const long long n = (long long)W * H;
+  for (int v = 0; v < 2; ++v) {
+    const uint32_t *pix = v ? pix1 : pix0;
+    const uint8_t *ok = v ? ok1 : ok0;
+    uint8_t *dis = v ? dis1 : dis0;
+    const unsigned int cnt = todo_cnt[v];
+    for (unsigned int k = wave; k < cnt; k += nwaves) {
+      const unsigned int i = todo[(size_t)v * n + k];
+      const int y = (int)(i / (unsigned int)W), x = (int)(i - (unsigned int)y * (unsigned int)W);
+      const uint32_t centre = pix[(size_t)y * Wp + pad + x];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hist[lane + 64 * j] = 0.0;
+      double total = 0.0;  // wave-uniform
+      const int qx = x - half_wnd + lane;
+      const bool col_in = lane <= 2 * half_wnd && qx >= 0 && qx < W;
+      const int y_lo = max(0, y - half_wnd), y_hi = min(H - 1, y + half_wnd);
+      for (int qy0 = y_lo; qy0 <= y_hi; qy0 += kMedianRows) {
+        int bin[kMedianRows];
+        double wgt[kMedianRows];
+        bool use[kMedianRows];
+#pragma unroll
+        for (int r = 0; r < kMedianRows; ++r) {  // independent gathers of up to kMedianRows window rows
+          const int qy = min(qy0 + r, y_hi);
+          const size_t q = (size_t)qy * W + (col_in ? qx : x);
+          use[r] = col_in && qy0 + r <= y_hi && ok[q] != 0;
+          bin[r] = dis[q];
+          wgt[r] = lut[__builtin_amdgcn_sad_u8(centre, pix[(size_t)qy * Wp + pad + (col_in ? qx : x)], 0u)];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < kMedianRows; ++r) {
+          // replay the row's additions in column order
+          for (unsigned long long pending = __builtin_amdgcn_ballot_w64(use[r]); pending; pending &= pending - 1) {
+            const int src = __builtin_ctzll(pending);
+            const int b = __builtin_amdgcn_readlane(bin[r], src);
+            const double w = lane_value(wgt[r], src);
+            if (lane == 0) hist[b] += w;
+            total += w;
+          }
+        }
+      }
+      wave_lds_fence();
+      const double half_total = total / 2.0;
+      if (half_total > 0.0) {  // else no consistent neighbour: the filled value stays
+        double run = 0.0;
+        int median = 0;
+        bool found = false;
+        for (int part = 0; part < 4 && !found; ++part) {
+          const double hp = hist[64 * part + lane];
+          for (int l = 0; l < 64; ++l) {
+            run += lane_value(hp, l);
+            if (run >= half_total) { median = 64 * part + l; found = true; break; }
+          }
+        }
+        if (lane == 0) dis[i] = (uint8_t)median;
+      }
+      wave_lds_fence();  // the bins are cleared for the next pixel only after they have been read
     }
   }
-  const double median_wgt = sum_wgt / 2.0;
-  sum_wgt = 0.0;
-  int median_disp = 0;
-  for (int d = 0; d < 256; ++d) {
-    sum_wgt += disp_hist[d];
-    if (sum_wgt >= median_wgt) { median_disp = d; break; }
-  }
-  if (median_wgt > 0.0) dis[i] = (uint8_t)median_disp;
 }
 
 // ------------------------------------------------------------------------------------------------

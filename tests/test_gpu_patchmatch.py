@@ -126,6 +126,44 @@ def test_postprocessing_bit_exact(gpu_ctx, mid_pair, name, scale_num, lam):
     assert np.mean(l != raw[0]) > 0.005  # the test is not vacuous: post-processing changed pixels
 
 
+def test_postprocessing_hand_made_fields(gpu_ctx):
+    """PostProcessing on plane fields chosen for its corner cases, 300 columns (more than the 256 lanes of the row scan):
+    a row without one consistent pixel (nothing to fill from), rows whose only consistent pixels sit at one end,
+    a fully consistent row, zero disparities (never consistent, cs_patchmatch.cc:362), and noise everywhere else."""
+    from crossscalepatchmatch_amd import synth
+    w, h, D = 300, 24, 16
+    l, r, _, _ = synth.make_pair(w, h, D, regions=3, seed=31)
+    pair = dict(l=l, r=r, max_dis=D)
+    pc, pm = _setup(gpu_ctx, pair, 0, 0.0)
+    pm.init(pc, seed=5, sum_order=po.SUM_DEVICE)
+    gpu_ctx.pm_init(seed=5)
+    rng = np.random.default_rng(7)
+    d = [rng.integers(0, D - 1, (h, w)).astype(np.float64) + rng.choice([0.0, 0.25, 0.5], (h, w)) for _ in (0, 1)]
+    for v in (0, 1):
+        d[v][0, :] = 5.0                      # row 0: consistent except where x -/+ 5 leaves the image
+        d[v][2, :] = 3.0; d[v][3, :] = 3.0
+    d[0][1, :] = 0.0; d[1][1, :] = 9.0        # row 1: left disparity 0 -> never consistent; right finds 0 vs 9 -> never
+    d[1][2, : w - 8] = 11.0                   # row 2: only the right end agrees
+    d[1][3, 8:] = 11.0                        # row 3: only the left end agrees
+    for v in (0, 1):
+        P = pm.planes(v)
+        P[..., 0:2] = 0.0; P[..., 2] = 1.0
+        P[..., 3] = np.arange(w)[None, :]; P[..., 4] = np.arange(h)[:, None]; P[..., 5] = d[v]
+        P[..., 6:8] = 0.0; P[..., 8] = d[v]
+        # slanted planes on a few rows so that FillInvalid's "smaller of the two planes at x" differs from both neighbours
+        P[5:9, :, 6] = rng.uniform(-0.2, 0.2, (4, w)); P[5:9, :, 8] = d[v][5:9] - P[5:9, :, 6] * np.arange(w)[None, :]
+        gpu_ctx.set_planes(v, np.concatenate([P[..., 0:3], P[..., 6:9]], -1), pm.min_cost(v))
+    pm.plane_to_disp()
+    raw = [gpu_ctx.disparity_u8(v, 4) for v in (0, 1)]
+    for v in (0, 1):
+        np.testing.assert_array_equal(raw[v], pm.dis(v))
+    pm.postprocess()
+    lo, ro = gpu_ctx.postprocess(4)
+    np.testing.assert_array_equal(lo, pm.dis(0))
+    np.testing.assert_array_equal(ro, pm.dis(1))
+    assert np.mean(lo != raw[0]) > 0.3                 # most of the noise was replaced
+
+
 def test_golden_pipeline_fixture(gpu_ctx):
     """The committed answer of tests/golden/make_golden.py (oracle-generated; the reference is unbuildable here)."""
     import os
