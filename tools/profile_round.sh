@@ -6,9 +6,6 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-# 1. the default bench line (three pairs in flight, CPU baseline) and the one-pair-at-a-time line
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_inflight1.json 2> /dev/null
 # 2. kernel trace of the one-pair-at-a-time command (average launch durations must agree with its hipEvent figures)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --in-flight 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_traced.json 2> /dev/null
@@ -19,6 +16,11 @@ cd $R
 tools/pmc_run.sh $TAG refine,sweep,view_eval,init -- python $R/bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/pmc_to_json.py gpurun_out/$TAG k_refine gpurun_out/$TAG/refine_pmc.json "bench.py --in-flight 1 --steps 1 --warmup 1 --no-cpu-baseline: C3, (1 warm-up + 1 timed) pairs x 3 iterations = 6 launches of k_refine<true,1>" > /dev/null
 python tools/pmc_to_json.py gpurun_out/$TAG k_spatial_sweep gpurun_out/$TAG/sweep_pmc.json "same command: 6 launches of k_spatial_sweep<true,1>" > /dev/null
+# 1. the default bench line (three pairs in flight, CPU baseline) and the one-pair-at-a-time line -- after the counter passes, so
+#    that the line quotes the counters of THIS build (profiles/refine_pmc.json is refused when its source hash differs)
+cp $O/refine_pmc.json profiles/refine_pmc.json
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_inflight1.json 2> /dev/null
 # 5. the other BASELINE.json configs (3 pairs in flight; C5 includes post-processing; C4 goes through batch.run_batch) -- for reference, not the headline
 for C in C1 C2 C4 C5; do
   S=6; [ $C = C5 ] && S=3
