@@ -222,8 +222,8 @@ __device__ __forceinline__ double lane_value(double v, int src_lane) {  // src_l
 constexpr int kMedianBlock = 256;
 constexpr int kMedianRows = 6;  // window rows whose loads are in flight together
 // WeightedMedian(valid, 35, WMF_GAMMA) (:430-506): inconsistent pixels only, consistent neighbours only.  2*half_wnd+1 <= 64.
-// The 256 bins live in the wave's 2 KB of LDS; one lane replays the additions in window order (same-bin additions are a
-// dependent chain whatever the layout, and so is the running total), the other lanes' work is the gather that feeds it.
+// The 256 bins live in the wave's 2 KB of LDS; the additions are replayed in window order (same-bin additions are a dependent
+// chain whatever the layout, and so is the running total), the lanes' parallel work is the gather that feeds the replay.
 __global__ __launch_bounds__(kMedianBlock) void k_weighted_median(const uint32_t *__restrict__ pix0, const uint32_t *__restrict__ pix1, int Wp, int pad,
                                                                   int W, int H, const uint8_t *__restrict__ ok0, const uint8_t *__restrict__ ok1,
                                                                   const double *__restrict__ lut, uint8_t *__restrict__ dis0, uint8_t *__restrict__ dis1,
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kMedianBlock) void k_weighted_median(const uint32_t
       const uint32_t centre = pix[(size_t)y * Wp + pad + x];
 #pragma unroll
       for (int j = 0; j < 4; ++j) hist[lane + 64 * j] = 0.0;
-      double total = 0.0;  // wave-uniform
+      double total = 0.0, open_val = 0.0;  // wave-uniform
+      int open_bin = -1;
       const int qx = x - half_wnd + lane;
       const bool col_in = lane <= 2 * half_wnd && qx >= 0 && qx < W;
       const int y_lo = max(0, y - half_wnd), y_hi = min(H - 1, y + half_wnd);
@@ -271,11 +272,17 @@ __global__ __launch_bounds__(kMedianBlock) void k_weighted_median(const uint32_t
             const int src = __builtin_ctzll(pending);
             const int b = __builtin_amdgcn_readlane(bin[r], src);
             const double w = lane_value(wgt[r], src);
-            if (lane == 0) hist[b] += w;
+            if (b != open_bin) {  // neighbours mostly share a disparity: the open bin stays in a register until another one is hit
+              if (lane == 0 && open_bin >= 0) hist[open_bin] = open_val;
+              open_val = hist[b];
+              open_bin = b;
+            }
+            open_val += w;
             total += w;
           }
         }
       }
+      if (lane == 0 && open_bin >= 0) hist[open_bin] = open_val;
       wave_lds_fence();
       const double half_total = total / 2.0;
       if (half_total > 0.0) {  // else no consistent neighbour: the filled value stays
