@@ -90,3 +90,30 @@ def test_effective_cpus_is_bounded_by_what_the_container_may_use():
         assert n <= len(os.sched_getaffinity(0))
     except AttributeError:
         pass
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/cspm.h is the boundary a cgo / JNI / ctypes binding is written against: it must compile as pedantic C99 (no C++
+    in the signatures) and a C program must link against the shared library and get a status code -- not an exception -- back."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "crossscalepatchmatch_amd")
+    src = tmp_path / "bind.c"
+    src.write_text('#include <stdio.h>\n#include "cspm.h"\n'
+                   "int main(void) {\n"
+                   "  cspm_ctx *ctx = NULL;\n"
+                   "  int rc = cspm_create(&ctx, 1 << 20);  /* no such device anywhere: an error code either way */\n"
+                   '  printf("%d|%s\\n", rc, cspm_last_error(NULL));\n'
+                   "  if (ctx) cspm_destroy(ctx);\n"
+                   "  return rc == CSPM_OK;\n"
+                   "}\n")
+    exe = tmp_path / "bind"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lcspm_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rc, msg = out.stdout.strip().split("|", 1)
+    assert int(rc) < 0 and msg  # a negative status and a message
