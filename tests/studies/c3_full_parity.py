@@ -1,14 +1,14 @@
 """One whole C3 pair (BASELINE.json configs[2]: 1242x375, max_dis 128, GRD, 5 levels, lambda 0.3, 3 iterations, raster sweeps) through
 the HIP path and through the CPU oracle in the same device order: every plane, every stored cost and both 8-bit maps must be
 identical.  The GPU suite checks C3 on samples and properties (the oracle needs minutes for the pair); this is the full check,
-run once per round on the GPU box:  python tools/c3_full_parity.py [pair index] > profiles/rNN_c3_full_parity.txt"""
+run once per round on the GPU box:  python tests/studies/c3_full_parity.py [pair index] > profiles/rNN_c3_full_parity.txt"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from crossscalepatchmatch_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 

@@ -6,13 +6,13 @@ test with LB = 0).  The script runs PatchMatch on the GPU (C3 by default), takes
 draws refinement candidates exactly as PlaneRefinement does (cs_patchmatch.cc:292-345) for runs of 64 adjacent pixels (= one
 wavefront of the row engine), evaluates their per-level costs with the oracle, and reports per halving step the fraction of
 lanes -- and of whole wavefronts -- whose rejection is proven after each level, with LB = 0 and with the bound.
-Usage (GPU box): python tools/lb_exit_study.py [C3|C2] [n_runs]"""
+Usage (GPU box): python tests/studies/lb_exit_study.py [C3|C2] [n_runs]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import crossscalepatchmatch_amd as cs
 from crossscalepatchmatch_amd import synth
