@@ -57,7 +57,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline_on(name, device_index=0):
+def cpu_baseline_on(name, device_index=0, crop=None):
     """The oracle (kind "port": the reference itself needs OpenCV/gflags and cannot be built here) in REFERENCE ORDER
     (serial raster sweep, serial window sum, OpenMP over the rows of init/refinement as the reference) on the whole of one
     BASELINE.json config on this box's host cores, next to the GPU on the same pair, seed and schedule -- which also gives
@@ -66,6 +66,11 @@ def cpu_baseline_on(name, device_index=0):
     import crossscalepatchmatch_amd as cs
     from crossscalepatchmatch_amd import synth
     cfg, l, r, _, _ = synth.make_config(name)
+    full_w = cfg["w"]
+    if crop:  # a centred column band of the pair (both images, same columns): a bounded sample of the same workload
+        x0 = (cfg["w"] - crop) // 2
+        l, r = np.ascontiguousarray(l[:, x0:x0 + crop]), np.ascontiguousarray(r[:, x0:x0 + crop])
+        cfg = dict(cfg, w=crop)
     threads = max(1, min(po.effective_cpus(), cfg["h"]))  # the cores this process may use (cgroup quota), not the visible count
     t0 = time.perf_counter()
     pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
@@ -85,11 +90,21 @@ def cpu_baseline_on(name, device_index=0):
     gdt = time.perf_counter() - t1
     taps = g.taps_per_view_pass() * 2 * (pm.evals() // (2 * cfg["w"] * cfg["h"]))
     diff = [np.abs(g.disparity_f64(v) - pm.disp_f64(v)) for v in (0, 1)]
+    extra = {}
+    if crop:  # what the whole pair would take at this tap rate -- EXTRAPOLATED by the exact in-image tap counts, labelled as such
+        lf, rf = synth.make_config(name)[1:3]
+        g.set_images(lf, rf)
+        g.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+        full_taps = g.taps_per_view_pass() * 2 * (pm.evals() // (2 * cfg["w"] * cfg["h"]))
+        extra["whole_pair_extrapolated"] = {"seconds": dt * full_taps / taps, "value": full_w * cfg["h"] / 1e6 / (dt * full_taps / taps), "unit": "Mpix/s",
+                                            "note": f"extrapolated, not measured: crop time x (taps of the whole {full_w}x{cfg['h']} pair / taps of the crop) "
+                                                    f"= x {full_taps / taps:.3f}"}
     g.close()
     mpix = cfg["w"] * cfg["h"] / 1e6
     return {
         "value": mpix / dt, "unit": "Mpix/s", "cores": threads, "kind": "port",
-        "sample": f"the whole of {name}: {cfg['w']}x{cfg['h']} max_dis={cfg['max_dis']} GRD "
+        "sample": (f"a centred {crop}-column crop of {name} ({full_w}x{cfg['h']})" if crop else f"the whole of {name}") +
+                  f": {cfg['w']}x{cfg['h']} max_dis={cfg['max_dis']} GRD "
                   f"{'cross-scale (5 levels, lambda 0.3)' if cfg['scale_num'] else 'single scale'}, 3 iterations, "
                   f"reference order (serial raster sweep, serial window sum), OpenMP over the rows of init/refinement as the reference; "
                   f"{dt:.1f} s, {taps / dt / 1e9:.3f} Gtap/s",
@@ -99,15 +114,21 @@ def cpu_baseline_on(name, device_index=0):
         "gpu_vs_cpu_bad0.5": float(np.mean([np.mean(d > 0.5) for d in diff])),
         "gpu_vs_cpu_bad2.0": float(np.mean([np.mean(d > 2.0) for d in diff])),
         "gpu_vs_cpu_max_abs_px": float(max(d.max() for d in diff)),
+        **extra,
     }
 
 
 def cpu_baseline(device_index=0):
-    """BASELINE.json's metric is quoted on the cross-scale cost: the CPU leg runs the whole of C2 (configs[1], 450x375, D=60,
-    5 levels -- the reference's cross-scale path pre_cs_pc.cc:133-188; 1-2 minutes of host time) and, as before, the whole of
-    C1 (configs[0], single scale, the reference's own CPU-runnable case)."""
-    out = cpu_baseline_on("C2", device_index)
-    out["sample"] += " (BASELINE.json configs[1])"
+    """The headline configuration first: C3 (configs[2], 1242x375, D=128, 5 levels) on a centred 320-column crop at full height and
+    full disparity range -- about a minute of host time in the reference's order (its raster sweep is serial); the whole pair would
+    take about four (the figure extrapolated by exact tap counts is given and labelled).  Then, as before, the whole of C2
+    (configs[1], 450x375, D=60, 5 levels: the reference's cross-scale path pre_cs_pc.cc:133-188) and the whole of C1 (configs[0],
+    single scale, the reference's own CPU-runnable case).  Every leg also runs the GPU on the same inputs: the north-star parity
+    figure (disparities within 0.5 px of the reference-order CPU result)."""
+    out = cpu_baseline_on("C3", device_index, crop=320)
+    out["sample"] += " (BASELINE.json configs[2], the configuration `value` is measured on)"
+    out["c2_cross_scale"] = cpu_baseline_on("C2", device_index)
+    out["c2_cross_scale"]["sample"] += " (BASELINE.json configs[1])"
     out["c1_single_scale"] = cpu_baseline_on("C1", device_index)
     return out
 
@@ -125,6 +146,7 @@ def main():
     ap.add_argument("--rb-rounds", type=int, default=1)
     ap.add_argument("--no-early-exit", action="store_true")
     ap.add_argument("--volumes", action="store_true", help="materialise f64 cost volumes (reference data flow) instead of fused cells")
+    ap.add_argument("--sweep-pairs", action="store_true", help="raster sweep on paired-cell volumes (CSPM_OPT_SWEEP_PAIRS) instead of the fused cells")
     ap.add_argument("--raster-launches", action="store_true", help="raster sweep as one launch per anti-diagonal instead of the persistent kernel")
     ap.add_argument("--cc", default="GRD", choices=["GRD", "CEN", "IMG"],
                     help="cost function (BASELINE.json's metric is GRD; CEN = census; IMG = the volume-free GrdPC / CSPC plane costs, for comparison)")
@@ -164,9 +186,17 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    if world > 1:
+    force_dist = os.environ.get("CSPM_BENCH_FORCE_DIST", "0") == "1"  # a process group (and C4's collectives) even at world size 1: RCCL on a one-GPU box
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
@@ -222,7 +252,10 @@ def main():
         if args.cc == "IMG":
             ctx.build_cost_img(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
         else:
-            (ctx.build_cost_grd if args.cc == "GRD" else ctx.build_cost_cen)(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
+            if args.cc == "GRD":
+                ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes, sweep_pairs=args.sweep_pairs)
+            else:
+                ctx.build_cost_cen(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=args.volumes)
         ctx.patchmatch(3, **pm_kw)
         if use_pp:  # PatchMatch(iter_num, plane_cost, use_pp = true): post-processing is inside the reference's timed region (main.cc:92-126)
             ctx.postprocess_device(cfg["dis_scale"], out[0].data_ptr(), out[1].data_ptr())
@@ -241,7 +274,7 @@ def main():
     def run_batch_once(count_per_rank):
         sub = batch_pairs[: count_per_rank * world] if rank == 0 else None
         fn = pair_fn if batch_dev.type == "cuda" else _ViaHost()
-        return batch.run_batch(sub, batch_params if rank == 0 else None, fn, device=str(batch_dev), dist=dist)
+        return batch.run_batch(sub, batch_params if rank == 0 else None, fn, device=str(batch_dev), dist=dist, force_collectives=force_dist)
 
     if batch_mode:
         if args.warmup:
@@ -297,6 +330,7 @@ def main():
             "config": {"workload": f"{args.config}: {w}x{h} max_dis={cfg['max_dis']} GRD scale_num={cfg['scale_num']} "
                                    f"reg_lambda={cfg['reg_lambda']} wnd=35 iters=3 (BASELINE.json configs[2] when C3)",
                        "cc_name": args.cc, "cost_source": "volumes" if args.volumes else "fused", "schedule": args.schedule,
+                       "sweep_cells": "paired-cell volumes" if ctxs[0].get_option(capi.OPT_SWEEP_PAIRS_ACTIVE) else "as cost_source",
                        "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds,
                        "early_exit": not args.no_early_exit, "pairs_per_gpu": args.steps, "distinct_pairs_per_gpu": npairs, "pairs_in_flight_per_gpu": nfl, "use_pp": use_pp,
                        "parallelism": f"{world} rank(s), one per GPU, {nfl} independent pair stream(s) each",
@@ -349,6 +383,44 @@ def main():
             else:
                 roof["pmc_note"] = ("no committed PMC file for these kernels (source hash mismatch or another workload): instruction-level "
                                     "figures omitted rather than quoted stale")
+            # every plane-evaluating kernel against the same yardstick (one pair alone on the GPU), and the whole pair as timed
+            pass_taps = alg_taps / 2.0  # one evaluation of every pixel of ONE view
+            per_view_evals = {
+                # InitRandomPlane: every pixel of both views once (cs_patchmatch.cc:115-148)
+                "init": ("k_init", 2.0 * w * h),
+                # SpatialPropagation: two evaluations per pixel as the reference performs them -- one in the first sweep row and
+                # column, none at the first pixel (cs_patchmatch.cc:178-213) -- both views per launch.  The kernel itself skips
+                # evaluations that cannot change the outcome (bitwise equal candidates): the yardstick does not
+                "spatial": ("k_spatial_sweep" if not args.raster_launches else "k_spatial_diag (all launches of a sweep)", 2.0 * (2.0 * w * h - w - h)),
+                # ViewPropagation: one candidate per source pixel, one target view per launch (cs_patchmatch.cc:229-277); candidates are
+                # evaluated at their target column -- the tap count of a uniform pass over the view is used
+                "view": ("k_view_eval", 1.0 * w * h),
+                "refine": ("k_refine", 2.0 * w * h * steps_per_launch),
+            }
+            kern = {}
+            sweeps_per_timed = 1 if not args.raster_launches else (w + h - 2)
+            for key, (kname, evals) in per_view_evals.items():
+                t = solo.get(key)
+                if not t or not t["launches"]:
+                    continue
+                launches = t["launches"] / (sweeps_per_timed if key == "spatial" else 1)
+                k_s = t["ms"] / launches / 1e3
+                k_ops = evals / (w * h) * pass_taps * OPS_PER_TAP
+                kern[key] = {"kernel": kname, "avg_launch_ms": k_s * 1e3, "launches_per_pair": launches, "algorithmic_evaluations_per_launch": evals,
+                             "algorithmic_ops_per_launch": k_ops, "frac": k_ops / k_s / F64_LANE_OPS_PEAK}
+            roof["kernels"] = kern
+            evals_per_pixel_view = sum(per_view_evals[k][1] / (2.0 * w * h) * (solo[k]["launches"] / (sweeps_per_timed if k == "spatial" else 1))
+                                       for k in per_view_evals if solo.get(k) and solo[k]["launches"])
+            pair_ops = evals_per_pixel_view * alg_taps * OPS_PER_TAP
+            roof["pair_frac"] = pair_ops / (dt / args.steps) / F64_LANE_OPS_PEAK
+            roof["pair_note"] = ("pair_frac = algorithmic operations of a whole pair (%.1f evaluations per pixel and view x in-image taps x 14) / ms_per_step "
+                                 "(the timed region, %d pair(s) in flight) / 3.93e13" % (evals_per_pixel_view, nfl))
+            spmc_file = os.path.join(ROOT, "profiles", "sweep_pmc.json")
+            spmc = json.load(open(spmc_file)) if os.path.exists(spmc_file) else None
+            if spmc and spmc.get("kernel_source_hash") == kernel_source_hash() and args.config in ("C3", "C4") and args.cc == "GRD" and not args.volumes and "spatial" in kern:
+                kern["spatial"].update({"pmc_file": os.path.relpath(spmc_file, ROOT), "td_busy_frac_pmc": spmc.get("td_busy_frac"), "ta_busy_frac_pmc": spmc.get("ta_busy_frac"),
+                                        "valu_winstr_per_launch_pmc": spmc.get("valu_winstr_per_launch"), "vmem_rd_instr_per_pixel_pmc": spmc.get("vmem_rd_instr_per_launch", 0) / (2.0 * w * h),
+                                        "traffic": spmc.get("hbm_bytes_per_launch"), "bound": "L1 return path (TD) + dependency chain of the anti-diagonals"})
             out["roofline"] = roof
         out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}  # with pairs in flight: overlapping brackets
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}

@@ -105,25 +105,32 @@ class HipPairFn:
                 c.close()
 
 
-def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4):
+def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4, force_collectives=False):
     """pairs: on rank 0 a uint8 array/tensor [n, 2, h, w, 3] (ignored elsewhere); params: dict with PARAM_KEYS on
     rank 0 ("cc" optional).  Returns on rank 0 a uint8 tensor [n, 2, h, w] (disparity maps in input order), None on other ranks.
 
     Dispatch: every rank owns a contiguous block of pairs.  The blocks travel in rounds of `chunk_pairs` pairs per rank
     (one scatter per round, the next round's scatter in flight while this round's pairs are being enqueued), straight out of
-    rank 0's copy of the batch: no per-rank padded staging copies, receive memory bounded by two chunks."""
+    rank 0's copy of the batch: no per-rank padded staging copies, receive memory bounded by two chunks.
+
+    A single rank needs no collective and skips them -- unless `force_collectives` (with an initialised process group): then the
+    broadcast, the chunked asynchronous scatter and the gather run with world size 1, which is how the RCCL code path (backend
+    "nccl": device tensors, views of the batch as scatter inputs, pair streams ordered against the collectives' stream) is
+    exercised on a one-GPU box."""
     import torch
     if dist is None or not dist.is_initialized():
         world, rank = 1, 0
+        force_collectives = False
     else:
         world, rank = dist.get_world_size(), dist.get_rank()
+    coll = world > 1 or bool(force_collectives)
     dev = torch.device(device)
     # 1. run parameters: one small broadcast from rank 0
     meta = torch.zeros(len(PARAM_KEYS) + 1, dtype=torch.float64, device=dev)
     if rank == 0:
         n = int(pairs.shape[0])
         meta = torch.tensor([float(params.get(k, 0)) for k in PARAM_KEYS] + [float(n)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if coll:
         dist.broadcast(meta, src=0)
     p = {k: meta[i].item() for i, k in enumerate(PARAM_KEYS)}
     n = int(meta[-1].item())
@@ -143,7 +150,7 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4):
                 dl, dr = pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q)
                 out[base + i, 0], out[base + i, 1] = dl, dr
 
-    if world > 1:
+    if coll:
         chunk = max(1, min(int(chunk_pairs), cap)) if cap else 1
         rounds = (cap + chunk - 1) // chunk
         src = torch.as_tensor(pairs, dtype=torch.uint8).to(dev) if rank == 0 else None
@@ -182,7 +189,7 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4):
     if fin is not None:
         fin()
     # 2. gather the 8-bit maps on rank 0
-    if world > 1:
+    if coll:
         got = [torch.zeros_like(out) for _ in range(world)] if rank == 0 else None
         dist.gather(out, got, dst=0)
         if rank != 0:

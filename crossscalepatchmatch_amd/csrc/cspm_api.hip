@@ -42,9 +42,10 @@ struct DevGuard {
 
 // what the buffers of a cost object were sized for: an identical request reuses them (no hipMalloc / hipFree per pair)
 struct CostKey {
-  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1;
+  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1, with_pairs = 0;
   bool operator==(const CostKey &o) const {
-    return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind;
+    return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind &&
+           with_pairs == o.with_pairs;
   }
 };
 enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2, kKindImg = 3 };
@@ -55,6 +56,9 @@ struct cspm_ctx {
   // is bound by its dependency chain; 1 is 43 % slower); the resident workgroups mostly wait, and every one of them holds
   // registers another pair's refinement could use: with three pairs in flight 2 gives 222.7 ms per pair, 3 gives 228.1.
   int sweep_wg_per_cu = 2;
+  int sweep_bands = 1;               // row bands of the persistent sweep (env CSPM_SWEEP_BANDS, up to 8; 1 = one queue for the whole image: the default,
+                                     // bands help only the paired-cell volumes)
+  int sweep_bands_built = 0;         // what d_sweep_start was filled for
   int refine_chunk = 64;  // PlaneRefinement halving steps per launch (tuning knob, env CSPM_REFINE_CHUNK)
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::string err;
@@ -80,6 +84,9 @@ struct cspm_ctx {
   bool is_img = false;           // cost built by cspm_build_cost_img (GrdPC / CSPC: no cells, no volumes)
   const uint32_t *cen_code[2][CSPM_MAX_LEVELS] = {{nullptr}};
   long long opt_grd_volumes = 0; // CSPM_OPT_GRD_VOLUMES
+  long long opt_sweep_pairs = 0;   // CSPM_OPT_SWEEP_PAIRS: 0 = never (default: measured no faster), 1 = when they fit
+  long long sweep_pairs_limit = 4LL << 30;  // bytes of paired-cell volumes a context may hold (env CSPM_SWEEP_PAIRS_MAX_MB)
+  bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   unsigned long long *d_maxkeys = nullptr;
   // plane field
   bool field_alloc = false;
@@ -104,6 +111,10 @@ struct cspm_ctx {
   int last_iters = 0;
   cspm_pm_params last_params{};
   long long sweep_fallbacks = 0;      // how often that happened (cspm_get_option)
+  // asynchronous outputs (cspm_disparity_u8_device / cspm_postprocess_device) enqueued behind a run whose sweep has not been checked
+  // yet: when that run is repeated after a timeout they are produced again from the repeated run's planes
+  struct OutReq { int post, view, dis_scale; void *o0, *o1; };
+  std::vector<OutReq> out_reqs;
   // CSPatchMatch over a foreign IPlaneCost (cspm_fpm_*): candidate buffers and what the pending batch was
   FpmCand fpm{nullptr, nullptr, nullptr, nullptr};
   long long fpm_cap = 0;
@@ -343,12 +354,28 @@ void launch_pyramid(cspm_ctx *c) {
 // allocate the (padded) pyramid images, the per-kind side arrays (gradients / census codes) and, when `with_vol`, the
 // cost volumes; fill Cost (everything except gradients / volume contents / max_cost).  An identical request (same
 // image size, max_dis, window, levels, kind, volumes) reuses every buffer: no allocator call, no host synchronisation.
-int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind) {
+int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind, bool want_pairs = false) {
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
   if (max_dis < 1 || wnd_size < 1 || wnd_size > kMaxWnd || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
     return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
+  // paired-cell volumes for the raster sweep (kSrcVol2): only when every level's indices fit the sweep's 28-bit element offsets
+  // and 24-bit slab size and the whole set stays under the context's budget (C3: 2.2 GB; C5 would need 56 GB and keeps the fused sweep)
+  bool with_pairs = false;
+  if (want_pairs) {
+    long long bytes = 0;
+    bool fits = true;
+    int W = c->W, H = c->H, D = max_dis;
+    for (int s = 0; s < (scale_num > 0 ? scale_num : 1); ++s) {
+      if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
+      const long long slab = (long long)W * H;
+      if (slab >= (1LL << 24) || slab * std::max(D, 1) >= (1LL << 28)) fits = false;
+      bytes += 2 * slab * std::max(D, 2) * 16;
+    }
+    with_pairs = fits && bytes <= c->sweep_pairs_limit;
+  }
   CostKey key;
   key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
+  key.with_pairs = with_pairs;
   const bool reuse = c->cost_alloc && key == c->cost_key;
   if (!reuse) free_cost(c);
   Cost &cd = c->cost;
@@ -387,6 +414,12 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         L.pix[v] = img;
         L.grd[v] = nullptr;
         L.vol[v] = nullptr;
+        L.vol2[v] = nullptr;
+        if (with_pairs) {
+          double2 *v2;
+          if ((rc = dalloc(c, &v2, (size_t)std::max(D, 2) * px, &c->cost_allocs))) return rc;  // slabs 0 .. D-1; a level with D < 2 is only ever addressed (slab 1), never used
+          L.vol2[v] = v2;
+        }
         if (with_vol) {
           double *vol;
           if ((rc = dalloc(c, &vol, (size_t)(D + 2) * px, &c->cost_allocs))) return rc;  // D+1 slabs and one guard slab (clamped taps of a level with D < 2)
@@ -452,6 +485,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   c->is_grd = false;
   c->is_cen = false;
   c->is_img = false;
+  c->sweep_pairs = false;
   return CSPM_OK;
 }
 
@@ -496,20 +530,27 @@ int ensure_field(cspm_ctx *c) {
   }
   if ((rc = dalloc(c, &c->d_todo, 2 * n + 2, nullptr))) return rc;
   // persistent sweep state: control words, per-pixel granules (tag zero = never written), diagonal start table
-  if ((rc = dalloc(c, &c->d_sweep_ctrl, 2, nullptr))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream));
+  if ((rc = dalloc(c, &c->d_sweep_ctrl, 2 + kSweepMaxBands, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, (2 + kSweepMaxBands) * sizeof(unsigned int), c->stream));
   if ((rc = dalloc(c, &c->d_sweep_gran, 2 * n * kGranPerPixel, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_gran, 0, sizeof(unsigned long long) * 2 * n * kGranPerPixel, c->stream));
   c->sweep_epoch = 0;
   {
+    // per row band b (sweep rows [b*H/nb, (b+1)*H/nb)): start[k] = the band's items (both views) on anti-diagonals < k
     const int nd = c->W + c->H - 1;
-    std::vector<unsigned int> start(nd + 1, 0);
-    for (int k = 0; k < nd; ++k) {
-      const int cnt = std::min(c->H - 1, k) - std::max(0, k - (c->W - 1)) + 1;
-      start[k + 1] = start[k] + 2u * (unsigned)cnt;
+    const int nb = std::max(1, std::min(std::min(c->sweep_bands, kSweepMaxBands), c->H));
+    std::vector<unsigned int> start((size_t)nb * (nd + 1), 0);
+    for (int b = 0; b < nb; ++b) {
+      const int y0 = (int)((long long)b * c->H / nb), y1 = (int)((long long)(b + 1) * c->H / nb);
+      unsigned int *st = start.data() + (size_t)b * (nd + 1);
+      for (int k = 0; k < nd; ++k) {
+        const int cnt = std::min(y1 - 1, k) - std::max(y0, k - (c->W - 1)) + 1;
+        st[k + 1] = st[k] + 2u * (unsigned)std::max(cnt, 0);
+      }
     }
     if ((rc = dalloc(c, &c->d_sweep_start, start.size(), nullptr))) return rc;
     HIPCHK(c, hipMemcpy(c->d_sweep_start, start.data(), start.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
+    c->sweep_bands_built = nb;
   }
   c->field_alloc = true;
   return CSPM_OK;
@@ -531,6 +572,8 @@ Pm make_pm(cspm_ctx *c, const cspm_pm_params *p) {
 // once).  It is looked at by every call that synchronises with the host anyway (cspm_synchronize, the getters, the
 // single-phase entry cspm_pm_spatial): cspm_patchmatch itself stays asynchronous.
 int run_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p);
+int enqueue_disp_u8(cspm_ctx *c, int view, int dis_scale, void *d_out);
+int enqueue_postprocess_device(cspm_ctx *c, int dis_scale, void *d_l_out, void *d_r_out);
 
 int check_sweep(cspm_ctx *c) {
   if (!c->sweep_pending) return CSPM_OK;
@@ -542,6 +585,8 @@ int check_sweep(cspm_ctx *c) {
   const bool phases = c->phases_unchecked;
   c->pm_runs_unchecked = 0;
   c->phases_unchecked = false;
+  const std::vector<cspm_ctx::OutReq> reqs = c->out_reqs;
+  c->out_reqs.clear();
   if (ctrl[1]) {
     (void)hipMemsetAsync(c->d_sweep_ctrl, 0, 2 * sizeof(unsigned int), c->stream);
     // A timeout is slowness (a shared or oversubscribed GPU, a profiler attached, many contexts in flight), not a wrong
@@ -554,6 +599,11 @@ int check_sweep(cspm_ctx *c) {
       int rc = run_patchmatch(c, c->last_iters, &c->last_params);
       c->opt_raster_launches = keep;
       c->pm_runs_unchecked = 0;
+      // the maps that were enqueued behind the aborted run were computed from its planes: produce them again
+      for (const auto &q : reqs) {
+        if (rc != CSPM_OK) break;
+        rc = q.post ? enqueue_postprocess_device(c, q.dis_scale, q.o0, q.o1) : enqueue_disp_u8(c, q.view, q.dis_scale, q.o0);
+      }
       if (rc == CSPM_OK) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         ++c->sweep_fallbacks;
@@ -605,6 +655,17 @@ inline void allow_lds(K kern, size_t shmem) {
     }                                                                                                             \
   } while (0)
 
+// the raster sweep reads the paired-cell volumes when the cost object carries them (GRD, fused): same cells, same order, same bits
+#define LAUNCH_SWEEP(kern, grid, block, shmem, ...)                                                              \
+  do {                                                                                                            \
+    if (c->sweep_pairs && c->cost.fused == kSrcGrd) {                                                             \
+      if (c->cost.cs) LAUNCH_ONE((kern<true, kSrcVol2>), grid, block, shmem, __VA_ARGS__);                        \
+      else LAUNCH_ONE((kern<false, kSrcVol2>), grid, block, shmem, __VA_ARGS__);                                  \
+    } else {                                                                                                      \
+      LAUNCH_CS(kern, grid, block, shmem, __VA_ARGS__);                                                           \
+    }                                                                                                             \
+  } while (0)
+
 int do_init(cspm_ctx *c, const cspm_pm_params *p) {
   const long long items = 2LL * c->W * c->H;
   Pm pm = make_pm(c, p);
@@ -639,6 +700,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     sw.gran[0] = c->d_sweep_gran;
     sw.gran[1] = c->d_sweep_gran + (size_t)c->W * c->H * kGranPerPixel;
     sw.start = c->d_sweep_start;
+    sw.nbands = c->sweep_bands_built;
     sw.epoch = ++c->sweep_epoch;
     sw.total = 2u * (unsigned)c->W * (unsigned)c->H;
     sw.timeout_ticks = c->sweep_timeout_ms * 100000LL;  // the constant clock ticks at 100 MHz
@@ -659,13 +721,16 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       }
     }
 #endif
-    HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, sizeof(unsigned int), c->stream));  // the claim counter; ctrl[1] is sticky
+    HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl + 2, 0, kSweepMaxBands * sizeof(unsigned int), c->stream));  // the claim counters; ctrl[1] is sticky
     int ncu = c->ncu;
-    const unsigned grid = (unsigned)std::min<long long>((long long)sw.total, (long long)ncu * c->sweep_wg_per_cu);  // more than fit is harmless: unclaimed work is all a late workgroup needs
+    // more workgroups than fit is harmless (unclaimed work is all a late workgroup needs); at least one per band, a multiple of
+    // the bands so that every band gets the same number
+    unsigned grid = (unsigned)std::max<long long>(sw.nbands, std::min<long long>((long long)sw.total, (long long)ncu * c->sweep_wg_per_cu));
+    grid = (grid + (unsigned)sw.nbands - 1) / (unsigned)sw.nbands * (unsigned)sw.nbands;
     const unsigned waves = sweep_waves(c);
     {
       Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
-      LAUNCH_CS(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
+      LAUNCH_SWEEP(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
     }
     c->sweep_pending = true;
   } else {
@@ -673,7 +738,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
       const long long items = 2LL * (ys_hi - ys_lo + 1);
       Timed t(c, CSPM_K_SPATIAL, items * 2);
-      LAUNCH_CS(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), sweep_shared_bytes((int)sweep_waves(c)), c->cost, pm, k, inc);
+      LAUNCH_SWEEP(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), sweep_shared_bytes((int)sweep_waves(c)), c->cost, pm, k, inc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -692,7 +757,7 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     }
     {
       Timed t(c, CSPM_K_MISC, 0);
-      hipLaunchKernelGGL(k_view_resolve, dim3(c->H), dim3(256), shmem, c->stream, pm, v, iter % 2 == 0 ? 0 : 1, c->vc);
+      LAUNCH_ONE(k_view_resolve, dim3(c->H), dim3(256), shmem, pm, v, iter % 2 == 0 ? 0 : 1, c->vc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -729,6 +794,52 @@ int run_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
   return CSPM_OK;
 }
 
+// PlaneToDisp + PostProcessing (cs_patchmatch.cc:103-107, 508-588) enqueued on the ctx stream; results in c->d_dis[v]
+int postprocess_enqueue(cspm_ctx *c, int dis_scale) {
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
+  const long long n = (long long)c->W * c->H;
+  const Level &L0 = c->cost.lv[0];
+  Timed t(c, CSPM_K_POST, 0);
+  for (int v = 0; v < 2; ++v)  // PlaneToDisp (cs_patchmatch.cc:103)
+    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_dis[v], (size_t)c->W);
+  unsigned int *todo_cnt = c->d_todo + 2 * (size_t)n;
+  HIPCHK(c, hipMemsetAsync(todo_cnt, 0, 2 * sizeof(unsigned int), c->stream));
+  // LeftRightCheck of both views (:516) on the maps as PlaneToDisp left them
+  hipLaunchKernelGGL(k_lr_check, dim3(ew_grid(2 * n)), dim3(256), 0, c->stream, c->d_dis[0], c->d_dis[1], c->W, c->H, dis_scale, c->d_valid[0],
+                     c->d_valid[1]);
+  // FillInvalid (:545): a workgroup per row and view
+  if (fill_rows_shmem(c->W) > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the row scan of FillInvalid");
+  LAUNCH_ONE(k_fill_rows, dim3(2u * (unsigned)c->H), dim3(kFillBlock), fill_rows_shmem(c->W), pm, dis_scale, c->d_valid[0], c->d_valid[1], c->d_dis[0],
+             c->d_dis[1], c->d_todo, todo_cnt);
+  // WeightedMedian(valid, 35, WMF_GAMMA) (:571-573): a wavefront per listed pixel; exp(-i/10) is the plane-cost LUT
+  hipLaunchKernelGGL(k_weighted_median, dim3((unsigned)c->ncu * 8u), dim3(kMedianBlock), 0, c->stream, L0.pix[0], L0.pix[1], L0.Wp, L0.pad, c->W,
+                     c->H, c->d_valid[0], c->d_valid[1], c->d_lut, c->d_dis[0], c->d_dis[1], c->d_todo, todo_cnt, 35 / 2);
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+
+// PlaneToDisp of one view into a device buffer (u8, packed W*H), enqueued on the ctx stream
+int enqueue_disp_u8(cspm_ctx *c, int view, int dis_scale, void *d_out) {
+  Pm pm{};
+  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
+  {
+    Timed t(c, CSPM_K_MISC, 0);
+    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid((long long)c->W * c->H)), dim3(256), 0, c->stream, pm, view, dis_scale,
+                       (uint8_t *)d_out, (size_t)c->W);
+  }
+  HIPCHK(c, hipGetLastError());
+  return CSPM_OK;
+}
+int enqueue_postprocess_device(cspm_ctx *c, int dis_scale, void *d_l_out, void *d_r_out) {
+  int rc = postprocess_enqueue(c, dis_scale);
+  if (rc) return rc;
+  void *outs[2] = {d_l_out, d_r_out};
+  for (int v = 0; v < 2; ++v)
+    HIPCHK(c, hipMemcpyAsync(outs[v], c->d_dis[v], (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
+  return CSPM_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -759,6 +870,9 @@ int cspm_create(cspm_ctx **out, int device) {
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("CSPM_REFINE_CHUNK")) c->refine_chunk = std::max(1, atoi(e));
   if (const char *e = getenv("CSPM_SWEEP_WG")) c->sweep_wg_per_cu = std::max(1, atoi(e));
+  if (const char *e = getenv("CSPM_SWEEP_BANDS")) c->sweep_bands = std::max(1, std::min(kSweepMaxBands, atoi(e)));
+  if (const char *e = getenv("CSPM_SWEEP_PAIRS")) c->opt_sweep_pairs = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
@@ -863,6 +977,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
   switch (key) {
     case CSPM_OPT_GRD_VOLUMES: c->opt_grd_volumes = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_RASTER_LAUNCHES: c->opt_raster_launches = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PAIRS: c->opt_sweep_pairs = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -878,6 +993,8 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_RASTER_LAUNCHES: *value = c->opt_raster_launches; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS: *value = c->sweep_timeout_ms; return CSPM_OK;
     case CSPM_OPT_SWEEP_FALLBACKS: *value = c->sweep_fallbacks; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PAIRS: *value = c->opt_sweep_pairs; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     default: return fail(c, CSPM_ERR_ARG, "unknown option");
   }
 }
@@ -887,7 +1004,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const bool with_vol = c->opt_grd_volumes != 0;
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindGrd);
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindGrd, !with_vol && c->opt_sweep_pairs != 0);
   if (rc) return rc;
   Cost &cd = c->cost;
   // gradients of both views per level (grd_cc.cpp:70-77); then the GRD cells of both views
@@ -911,11 +1028,12 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
       Timed t(c, CSPM_K_GRD, 0);
       hipLaunchKernelGGL((k_grd_volume<SrcU32, true>), dim3(stride_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
                          SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, 0, L.D + 1, v,
-                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s);
+                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s, (double2 *)L.vol2[v]);
     }
   }
   HIPCHK(c, hipGetLastError());
   cd.fused = with_vol ? kSrcVolume : kSrcGrd;
+  c->sweep_pairs = cd.lv[0].vol2[0] != nullptr;
   c->is_grd = true;
   return finish_cost(c, false);
 }
@@ -1245,6 +1363,7 @@ int cspm_patchmatch(cspm_ctx *c, int iter_num, const cspm_pm_params *p) {
   if (iter_num < 0 || iter_num > 15) return fail(c, CSPM_ERR_ARG, "iter_num out of range");
   c->last_iters = iter_num;
   c->last_params = *p;
+  c->out_reqs.clear();  // outputs requested behind an earlier run: that run can no longer be repeated (two runs unchecked = an error)
   ++c->pm_runs_unchecked;
   return run_patchmatch(c, iter_num, p);
 }
@@ -1293,24 +1412,20 @@ int cspm_disparity_u8_device(cspm_ctx *c, int view, int dis_scale, void *d_out) 
   if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
-  Pm pm{};
-  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
-  {
-    Timed t(c, CSPM_K_MISC, 0);
-    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid((long long)c->W * c->H)), dim3(256), 0, c->stream, pm, view, dis_scale,
-                       (uint8_t *)d_out, (size_t)c->W);
-  }
-  HIPCHK(c, hipGetLastError());
-  return CSPM_OK;
+  // asynchronous: when the run in front of it has an unchecked sweep, remember the request -- a repeated run (sweep timeout)
+  // writes the map again from ITS planes, so the caller never reads a map of the aborted run after a successful check
+  if (c->sweep_pending) c->out_reqs.push_back(cspm_ctx::OutReq{0, view, dis_scale, d_out, nullptr});
+  return enqueue_disp_u8(c, view, dis_scale, d_out);
 }
 
 int cspm_get_disparity_u8(cspm_ctx *c, int view, int dis_scale, uint8_t *out, size_t stride) {
-  if (!c || !out || stride < (size_t)c->W) return CSPM_ERR_ARG;
-  int rc = cspm_disparity_u8_device(c, view, dis_scale, c->d_dis[view < 0 || view > 1 ? 0 : view]);
-  if (rc) return rc;
+  if (!c || !out || view < 0 || view > 1 || stride < (size_t)c->W) return CSPM_ERR_ARG;
+  if (!c->field_alloc) return fail(c, CSPM_ERR_STATE, "no plane field yet");
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
-  if ((rc = check_sweep(c))) return rc;
+  int rc = check_sweep(c);  // BEFORE PlaneToDisp: a run repeated after a sweep timeout must be the one the map is computed from
+  if (rc) return rc;
+  if ((rc = enqueue_disp_u8(c, view, dis_scale, c->d_dis[view]))) return rc;
   HIPCHK(c, hipMemcpy2DAsync(out, stride, c->d_dis[view], c->W, c->W, c->H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return CSPM_OK;
@@ -1331,31 +1446,6 @@ int cspm_get_disparity_f64(cspm_ctx *c, int view, double *out) {
   hipLaunchKernelGGL(k_plane_to_disp_f64, dim3(ew_grid((long long)n)), dim3(256), 0, c->stream, pm, view, c->vc.cost);
   HIPCHK(c, hipMemcpyAsync(out, c->vc.cost, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return CSPM_OK;
-}
-
-// PlaneToDisp + PostProcessing (cs_patchmatch.cc:103-107, 508-588) enqueued on the ctx stream; results in c->d_dis[v]
-static int postprocess_enqueue(cspm_ctx *c, int dis_scale) {
-  Pm pm{};
-  pm.W = c->W; pm.H = c->H; pm.f[0] = c->f[0]; pm.f[1] = c->f[1];
-  const long long n = (long long)c->W * c->H;
-  const Level &L0 = c->cost.lv[0];
-  Timed t(c, CSPM_K_POST, 0);
-  for (int v = 0; v < 2; ++v)  // PlaneToDisp (cs_patchmatch.cc:103)
-    hipLaunchKernelGGL(k_plane_to_disp_u8, dim3(ew_grid(n)), dim3(256), 0, c->stream, pm, v, dis_scale, c->d_dis[v], (size_t)c->W);
-  unsigned int *todo_cnt = c->d_todo + 2 * (size_t)n;
-  HIPCHK(c, hipMemsetAsync(todo_cnt, 0, 2 * sizeof(unsigned int), c->stream));
-  // LeftRightCheck of both views (:516) on the maps as PlaneToDisp left them
-  hipLaunchKernelGGL(k_lr_check, dim3(ew_grid(2 * n)), dim3(256), 0, c->stream, c->d_dis[0], c->d_dis[1], c->W, c->H, dis_scale, c->d_valid[0],
-                     c->d_valid[1]);
-  // FillInvalid (:545): a workgroup per row and view
-  if (fill_rows_shmem(c->W) > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the row scan of FillInvalid");
-  LAUNCH_ONE(k_fill_rows, dim3(2u * (unsigned)c->H), dim3(kFillBlock), fill_rows_shmem(c->W), pm, dis_scale, c->d_valid[0], c->d_valid[1], c->d_dis[0],
-             c->d_dis[1], c->d_todo, todo_cnt);
-  // WeightedMedian(valid, 35, WMF_GAMMA) (:571-573): a wavefront per listed pixel; exp(-i/10) is the plane-cost LUT
-  hipLaunchKernelGGL(k_weighted_median, dim3((unsigned)c->ncu * 8u), dim3(kMedianBlock), 0, c->stream, L0.pix[0], L0.pix[1], L0.Wp, L0.pad, c->W,
-                     c->H, c->d_valid[0], c->d_valid[1], c->d_lut, c->d_dis[0], c->d_dis[1], c->d_todo, todo_cnt, 35 / 2);
-  HIPCHK(c, hipGetLastError());
   return CSPM_OK;
 }
 
@@ -1382,12 +1472,8 @@ int cspm_postprocess_device(cspm_ctx *c, int dis_scale, void *d_l_out, void *d_r
   if (dis_scale < 1 || !d_l_out || !d_r_out) return fail(c, CSPM_ERR_ARG, "bad dis_scale / outputs");
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
-  int rc = postprocess_enqueue(c, dis_scale);
-  if (rc) return rc;
-  void *outs[2] = {d_l_out, d_r_out};
-  for (int v = 0; v < 2; ++v)
-    HIPCHK(c, hipMemcpyAsync(outs[v], c->d_dis[v], (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
-  return CSPM_OK;
+  if (c->sweep_pending) c->out_reqs.push_back(cspm_ctx::OutReq{1, 0, dis_scale, d_l_out, d_r_out});  // see cspm_disparity_u8_device
+  return enqueue_postprocess_device(c, dis_scale, d_l_out, d_r_out);
 }
 
 int cspm_enable_timing(cspm_ctx *c, int on) {
@@ -1477,12 +1563,16 @@ int cspm_fpm_begin(cspm_ctx *c, int w, int h, int max_dis) {
     free_images(c);
     c->W = w; c->H = h;
   }
+  if (c->cost_alloc && c->max_dis != max_dis) {  // its levels, strips and init range were sized for the old disparity range
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_cost(c);
+  }
   c->max_dis = max_dis;
   c->field_consistent = false;
   c->phases_unchecked = true;
   int rc = ensure_field(c);
   if (rc) return rc;
-  const long long need = 2LL * w * h;
+  const long long need = std::max(2LL * w * h, 4LL * std::min(w, h));  // a diagonal batch holds 4 per pixel (tiny images)
   if (c->fpm_cap < need) {
     if ((rc = dalloc(c, &c->fpm.xy, (size_t)need * 2, nullptr)) || (rc = dalloc(c, &c->fpm.view, (size_t)need, nullptr)) ||
         (rc = dalloc(c, &c->fpm.plane, (size_t)need * 6, nullptr)) || (rc = dalloc(c, &c->fpm.cost, (size_t)need, nullptr)))
@@ -1508,9 +1598,10 @@ int cspm_fpm_candidates(cspm_ctx *c, int phase, int iter, int step, const cspm_p
   switch (phase) {
     case CSPM_FPM_INIT:
     case CSPM_FPM_REFINE: {
+      if (phase == CSPM_FPM_REFINE && (step < 0 || step > 64)) return fail(c, CSPM_ERR_ARG, "refinement step out of range");
       double z = c->max_dis / 2.0, nn = 1.0;  // cs_patchmatch.cc:95, cs_patchmatch.h:145; halved once per step (:342-343)
-      for (int k = 0; k < step; ++k) { z /= 2.0; nn /= 2.0; }
-      if (phase == CSPM_FPM_REFINE && (step < 0 || z < 0.1)) return fail(c, CSPM_ERR_ARG, "refinement step out of range");
+      for (int k = 0; k < step && k < 64; ++k) { z /= 2.0; nn /= 2.0; }
+      if (phase == CSPM_FPM_REFINE && z < 0.1) return fail(c, CSPM_ERR_ARG, "refinement step out of range");
       count = 2 * n;
       hipLaunchKernelGGL(k_fpm_point_cand, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, phase == CSPM_FPM_REFINE ? 1 : 0, iter, step, z, nn);
       break;
@@ -1557,7 +1648,7 @@ int cspm_fpm_commit(cspm_ctx *c, const double *cost) {
       const size_t shmem = (size_t)c->W * (sizeof(unsigned long long) + sizeof(unsigned int));
       if (shmem > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the view-propagation row resolver");
       hipLaunchKernelGGL(k_fpm_view_commit, dim3(ew_grid(count)), dim3(256), 0, c->stream, pm, c->fpm, c->vc);
-      hipLaunchKernelGGL(k_view_resolve, dim3(c->H), dim3(256), shmem, c->stream, pm, c->fpm_step, c->fpm_iter % 2 == 0 ? 0 : 1, c->vc);
+      LAUNCH_ONE(k_view_resolve, dim3(c->H), dim3(256), shmem, pm, c->fpm_step, c->fpm_iter % 2 == 0 ? 0 : 1, c->vc);
       break;
     }
     case CSPM_FPM_SPATIAL:

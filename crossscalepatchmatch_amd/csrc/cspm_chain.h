@@ -39,6 +39,7 @@ struct ChainLevel {
   int dirE;              // byte step towards larger disparity in the other view: -E (left view) or +E
   double sgn;            // 2*view-1 as a double (GrdPC / CSPC: other_x = q_x + (2*view-1)*q_disp)
   const double *vol;
+  const char *vol2;      // kSrcVol2: paired device cells, 16 bytes per (d, y, x)
   size_t slab;
   uint32_t Ip;
 };
@@ -58,7 +59,13 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
   A.Wp = L.Wp; A.pad = L.pad;
   A.has_valid = L.D >= 2;
   A.maxc = cd.max_cost[view * CSPM_MAX_LEVELS + s];
-  if (SRC == kSrcCen) {
+  A.vol2 = nullptr;
+  if (SRC == kSrcVol2) {
+    A.px = reinterpret_cast<const char *>(L.pix[view]); A.opx = A.px;  // colours only: the guide weight
+    A.Ip = L.pix[view][cy * L.Wp + L.pad + cx];
+    A.vol2 = reinterpret_cast<const char *>(L.vol2[view]);
+    A.Dm1 = max(L.D - 1, 1);  // a level with D < 2 has no valid tap (has_valid): the clamped disparity only forms an address, slab 1 exists
+  } else if (SRC == kSrcCen) {
     A.px = reinterpret_cast<const char *>(L.pc[view]); A.opx = reinterpret_cast<const char *>(L.pc[1 - view]);
     A.Ip = L.pc[view][cy * L.Wp + L.pad + cx].pix;
   } else {
@@ -78,7 +85,7 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
 template <int SRC, int NC>
 __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainPlane (&pl)[NC], int lane,
                                              int pass_first, int pass_step, double S[NC][kMaxPasses]) {
-  constexpr int E = elem_size<SRC>();
+  constexpr int E = SRC == kSrcVol2 ? 4 : elem_size<SRC>();
   const int lutzero = kLutZero;
   const int lr = lane / kRowMod, j = lane - lr * kRowMod;  // lane 63: lr = 9 -> never a valid chain
 #pragma unroll
@@ -100,8 +107,10 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
       const double xg = (double)(A.ox0 + kRowMod * st);  // q_x of the group's first column
       const int dx = j + kRowMod * st;
       const bool ok = chain_ok & (dx < A.n) & ((unsigned)(qx0 + kRowMod * st) < (unsigned)A.W);
-      const uint4 P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
-      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, pix_of<SRC>(P), 0u);
+      uint4 P;
+      if constexpr (SRC == kSrcVol2) P = uint4{0u, 0u, *reinterpret_cast<const uint32_t *>(A.px + (size_t)(unsigned)(ob + st * (kRowMod * E))), 0u};
+      else P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
+      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, SRC == kSrcVol2 ? P.z : pix_of<SRC>(P), 0u);
       const int sad = ok ? sad0 : lutzero;  // masked taps get weight entry kLutZero = 0.0: they add +0.0
       const double wgt = lut.w[sad];        // :161-164
 #pragma unroll
@@ -118,7 +127,14 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
         }
         const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
         double c0, c1;
-        if (SRC == kSrcVolume) {
+        if constexpr (SRC == kSrcVol2) {
+          // one 16-byte gather: {cell(f), cell(f+1)} of this tap's pixel.  Masked taps (weight 0) read the window centre's column.
+          const int qy = A.oy0 + dy, qx = ok ? qx0 + kRowMod * st : A.ox0 + cd.half;
+          const unsigned idx = __umul24((unsigned)d.f, (unsigned)A.slab) + (unsigned)(qy * A.W + qx);  // < 2^28 (alloc_cost checks)
+          const double2 cc = *reinterpret_cast<const double2 *>(A.vol2 + (size_t)(idx << 4));
+          c0 = cc.x;
+          c1 = cc.y;
+        } else if (SRC == kSrcVolume) {
           const int qy = A.oy0 + dy, qx = ok ? qx0 + kRowMod * st : A.ox0 + cd.half;
           const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
           c0 = v[0];
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 #define CSPM_SWEEP_WPL 1
 #endif
 constexpr int kSweepWpl = CSPM_SWEEP_WPL;  // waves per pyramid level in a cross-scale sweep workgroup
-constexpr int kSweepMaxWaves = 16;
+constexpr int kSweepMaxWaves = CSPM_MAX_LEVELS * kSweepWpl > kMaxPasses ? CSPM_MAX_LEVELS * kSweepWpl : kMaxPasses;  // cross-scale: a wave per level (x kSweepWpl); single scale: a wave per chain pass
 
 // views into the dynamic LDS of a sweep launch: sized by the waves actually launched (sweep_shared_bytes), so that a second
 // kernel -- another stereo pair's refinement -- still finds LDS on the CU
@@ -435,22 +451,34 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd,
 // already holds the data -- no separate flag, no producer-side drain, no second round trip (a flag + payload hand-over
 // costs 1.7-1.9x a granule hand-over on this chip).  8-byte accesses are single-copy atomic, so a granule is never torn and
 // needs no ordering against the others.  No fences, no reliance on placement or dispatch order.  Deadlock freedom: pixels
-// are claimed in an order in which predecessors come first, so every granule a workgroup waits for belongs to a pixel
-// already claimed by a running workgroup.  Every spin is bounded (wall clock); a timeout raises ctrl[1] and all workgroups
-// drain.  The plane field itself (what later kernels read) is written with plain stores: nobody reads it across workgroups
+// are claimed in an order in which predecessors come first (below), so every granule a workgroup waits for belongs to a pixel
+// that a running workgroup has claimed or will claim without waiting for us.  Every spin is bounded (wall clock); a timeout
+// raises ctrl[1] and all workgroups drain.
+//
+// Row bands (round 4).  The image rows are cut into `nbands` (8) bands; workgroup b mod 8 -- on MI355X: the workgroups of XCD
+// b mod 8, dispatch being round-robin over the XCDs -- pulls the pixels of ITS band in diagonal-major order from the band's own
+// counter.  The global order is unchanged (a pixel still waits for exactly its two predecessors); what changes is who evaluates
+// what: an XCD's L2 then only has to hold the window rows of a 47-row band instead of the whole anti-diagonal front (with the
+// paired-cell volumes the front of a KITTI pair is ~3 MB per view set against a 4 MiB L2: 8 % of the L2 requests missed).
+// Deadlock freedom with bands: within a band claims are in diagonal-major order, so a pixel's in-band predecessors are claimed
+// earlier; its predecessor in the band above belongs to a queue that never waits for this band (dependencies only point up
+// and left), so by induction over the bands every awaited pixel is reached as long as each band has one running workgroup --
+// the first `nbands` workgroups of the grid.  The plane field itself (what later kernels read) is written with plain stores: nobody reads it across workgroups
 // inside the sweep except its owner.
 // ------------------------------------------------------------------------------------------------
 constexpr int kGranPerPixel = 12;
+constexpr int kSweepMaxBands = 8;
 struct Sweep {
-  unsigned int *ctrl;         // [0] next item, [1] error (sticky)
+  unsigned int *ctrl;         // [1] error (sticky), [2 + b] next item of row band b
   unsigned long long *gran[2];  // per view, per pixel: kGranPerPixel data-tagged granules {32 bits of the final plane, epoch}
-  const unsigned int *start;  // start[k] = items (both views) on diagonals < k; W+H entries
+  const unsigned int *start;  // per band b, W+H entries: start[b * (W+H) + k] = the band's items (both views) on diagonals < k
+  int nbands;                 // row bands (sweep coordinates): band b = rows [b*H/nbands, (b+1)*H/nbands)
   unsigned int epoch, total;
   long long timeout_ticks;  // bound of one wait for a predecessor, in ticks of the 100 MHz constant clock
   long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
 };
 #ifdef CSPM_SWEEP_TRACE
-#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[(size_t)item * 8 + (slot)] = wall_clock64(); } while (0)
+#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[((size_t)2 * pm.W * by0 + item) * 8 + (slot)] = wall_clock64(); } while (0)
 #else
 #define SWEEP_STAMP(slot) do { } while (0)
 #endif
@@ -492,11 +520,16 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int ndiag = pm.W + pm.H - 1;
-  int k = 0;
+  const int band = (int)(blockIdx.x % (unsigned)sw.nbands);
+  const int by0 = (int)((long long)band * pm.H / sw.nbands), by1 = (int)((long long)(band + 1) * pm.H / sw.nbands);  // sweep rows [by0, by1)
+  const unsigned int *bstart = sw.start + (size_t)band * (size_t)(ndiag + 1);
+  const unsigned int btotal = bstart[ndiag];
+  unsigned int *claim = &sw.ctrl[2 + band];
+  int k = by0;  // the band's first diagonal
   unsigned int next_item = 0;
   if (threadIdx.x == 0) {
-    if (__hip_atomic_load(&sw.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) next_item = sw.total;  // an earlier sweep failed
-    else next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_load(&sw.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) next_item = btotal;  // an earlier sweep failed
+    else next_item = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (;;) {
     if (threadIdx.x == 0) {
@@ -504,19 +537,19 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
       s_ok = 1;
       // claim the following item now: the atomic's latency hides behind this item's work.  Claims of a
       // workgroup stay increasing, which is all the deadlock argument needs.
-      if (next_item < sw.total) next_item = __hip_atomic_fetch_add(&sw.ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (next_item < btotal) next_item = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const unsigned int item = s_item;
-    if (item >= sw.total) return;
+    if (item >= btotal) return;
     SWEEP_STAMP(0);
 #ifdef CSPM_SWEEP_TRACE
-    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + (size_t)item * 8 : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; } }
+    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + ((size_t)2 * pm.W * by0 + item) * 8 : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; } }
 #endif
-    while (k + 1 < ndiag && item >= sw.start[k + 1]) ++k;  // items of one workgroup only increase
-    const int ys_lo = max(0, k - (pm.W - 1)), ys_hi = min(pm.H - 1, k);
+    while (k + 1 < ndiag && item >= bstart[k + 1]) ++k;  // items of one workgroup only increase
+    const int ys_lo = max(by0, k - (pm.W - 1)), ys_hi = min(by1 - 1, k);
     const int cnt = ys_hi - ys_lo + 1;
-    const int r = (int)(item - sw.start[k]);
+    const int r = (int)(item - bstart[k]);
     const int v = r / cnt;
     const int ys = ys_lo + (r - v * cnt), xs = k - ys;
     const int x = inc > 0 ? xs : pm.W - 1 - xs, y = inc > 0 ? ys : pm.H - 1 - ys;

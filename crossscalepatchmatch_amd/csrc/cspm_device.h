@@ -48,6 +48,9 @@ enum { kSrcVolume = 0, kSrcGrd = 1, kSrcCen = 2,
        kSrcImg = 3 };  // GrdPC / CSPC (plane_cost/grd_pc.cc, cspc.cc): no cells at all -- the other view's colour and gradient are
                        // interpolated at the real-valued column x -+ q_disp.  Elements are PixG with g = Sobel of the 8U gray image;
                        // the pad cells hold the WRAPPED image columns (HandleBorder, commfunc.h:129-145), so no border branch either
+enum { kSrcVol2 = 4 };  // raster sweep only (chain engine): GRD device cells materialised as PAIRS, vol2[d][y][x] = {cell(d), cell(d+1)} --
+                        // the two cells a tap interpolates between (pre_cs_pc.cc:171-176) arrive with ONE 16-byte gather, the guide
+                        // weight needs one 4-byte gather of the own colour: 2 gathers / 20 B per tap instead of 3 / 36 B
 
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
@@ -60,6 +63,7 @@ struct Level {
   const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
   const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only
   const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; null when fused
+  const double2 *vol2[2]; // kSrcVol2: D slabs of H*W pairs {cell(d), cell(d+1)} of the DEVICE cells (same bits as grd_cell()); null unless built
   double wgt;             // scale_wgt_[s]
 };
 

@@ -871,6 +871,9 @@ __device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, con
 #ifndef CSPM_ROW_BAND
 #define CSPM_ROW_BAND 4
 #endif
+#ifndef CSPM_ROW_VERT
+#define CSPM_ROW_VERT 0
+#endif
 constexpr int kRowBand = CSPM_ROW_BAND;
 struct RowItem {
   int v, y, x0;
@@ -889,12 +892,18 @@ __device__ __forceinline__ bool row_item(int W, int H, int views, RowItem &it) {
   const int per_blk = kRowBand * segs;
   const int blk_local = (int)(e / per_blk);
   const int rem = (int)(e - (long long)blk_local * per_blk);
-  const int row_in_blk = rem / segs;
+#if CSPM_ROW_VERT
+  // the waves of a workgroup (consecutive e) take the SAME 64-column segment of vertically adjacent rows: their 35-row windows
+  // overlap 31/35, so the strip rows one wave fetches are in the CU's L1 / the XCD's L2 when the next wave asks for them
+  const int seg = rem / kRowBand, row_in_blk = rem - seg * kRowBand;
+#else
+  const int row_in_blk = rem / segs, seg = rem - row_in_blk * segs;
+#endif
   const int row = (blk_local * 8 + xcd) * kRowBand + row_in_blk;  // row of the stacked views
   if (row >= views * H) return false;
   it.v = row / H;
   it.y = row - it.v * H;
-  it.x0 = (rem - row_in_blk * segs) * kWave;
+  it.x0 = seg * kWave;
   return true;
 }
 

@@ -90,6 +90,16 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * CSPM_OPT_SWEEP_FALLBACKS (read only): how many times that happened on this context. */
 #define CSPM_OPT_SWEEP_TIMEOUT_MS 3
 #define CSPM_OPT_SWEEP_FALLBACKS 4
+/* CSPM_OPT_SWEEP_PAIRS (set before cspm_build_cost_grd; GRD with fused cells only; default 0): 1 = when they fit the context's
+ * budget (4 GiB; a KITTI-size pair needs 2.2 GB, a 3000x2000 D=256 pair would need 56 GB and does without), the cost
+ * constructor also materialises the GRD cells as PAIRS {cell(d), cell(d+1)} per (d, y, x) -- the two f64 cells a tap interpolates
+ * between (pre_cs_pc.cc:171-176) -- and the raster sweep (SpatialPropagation, whose taps are gathers) reads one pair per tap instead
+ * of recomputing two cells from three image gathers; every other kernel keeps the fused cells.  Same cells, same order: identical
+ * planes.  Measured on MI355X: no faster than the fused sweep (20.4 vs 20.2 ms per sweep of a KITTI-size pair; the 16-byte gathers
+ * into a 1 GB volume cost the L1 return path more than the three 12-byte image gathers they replace), hence off by default.
+ * CSPM_OPT_SWEEP_PAIRS_ACTIVE (read only): 1 when the current cost object carries the pairs. */
+#define CSPM_OPT_SWEEP_PAIRS 5
+#define CSPM_OPT_SWEEP_PAIRS_ACTIVE 6
 int cspm_get_option(cspm_ctx *ctx, int key, long long *value);
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on
@@ -151,7 +161,9 @@ int cspm_set_planes(cspm_ctx *ctx, int view, const double *norm_param, const dou
 /* PlaneToDisp + dis() (cs_patchmatch.cc:590-601, 111-113): saturate_u8(Round2Int(d*dis_scale)) */
 int cspm_get_disparity_u8(cspm_ctx *ctx, int view, int dis_scale, uint8_t *out, size_t stride);
 int cspm_get_disparity_f64(cspm_ctx *ctx, int view, double *out); /* unquantised a*x+b*y+c */
-/* device-resident result (u8, packed w*h) for the batch driver */
+/* device-resident result (u8, packed w*h) for the batch driver.  Asynchronous; when the PatchMatch run in front of it is repeated
+ * after a sweep timeout (CSPM_OPT_SWEEP_TIMEOUT_MS), the map is written again from the repeated run's planes before the
+ * synchronising call returns success. */
 int cspm_disparity_u8_device(cspm_ctx *ctx, int view, int dis_scale, void *d_out);
 /* PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps */
 int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride);
@@ -172,7 +184,7 @@ int cspm_postprocess_device(cspm_ctx *ctx, int dis_scale, void *d_l_out, void *d
  *                           y-predecessor's plane, xy[2i] = -1 where the pixel has no such predecessor (:163-216)
  *   phase CSPM_FPM_VIEW    (step = target view): w*h candidates, one per source pixel of the other view (:229-277)
  *   phase CSPM_FPM_REFINE  (step = halving step 0 ..): 2*w*h candidates                            (:292-345)
- * Arrays must hold 2*w*h candidates.  Synchronous.  Afterwards cspm_get_planes / cspm_get_disparity_* / cspm_postprocess
+ * Arrays must hold max(2*w*h, 4*min(w,h)) candidates.  Synchronous.  Afterwards cspm_get_planes / cspm_get_disparity_* / cspm_postprocess
  * (which needs cspm_set_images for the weighted median) read the result as usual. */
 #define CSPM_FPM_INIT 0
 #define CSPM_FPM_SPATIAL 1

@@ -782,7 +782,7 @@ struct csor_pm {
   long long evals;
 };
 
-static const csor_pm_opts k_default_opts = {12345, CSOR_RNG_PER_PIXEL, CSOR_SCHED_RASTER, CSOR_SUM_SERIAL, 1, 4, 0};
+static const csor_pm_opts k_default_opts = {12345, CSOR_RNG_PER_PIXEL, CSOR_SCHED_RASTER, CSOR_SUM_SERIAL, 1, 4, 0, 0};
 
 /* cs_patchmatch.cc:3-34 */
 csor_pm *csor_pm_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h, int max_dis, int dis_scale) {
@@ -902,6 +902,38 @@ static void spatial_raster(csor_pm *pm, int cur_iter, const csor_pc *pc, const c
   }
 }
 
+/* The same sweep, anti-diagonal by anti-diagonal (csor_pm_opts.wavefront): sweep coordinates xs + ys = k; the in-place serial loop
+ * above makes (x,y) depend on (x-inc,y) and (x,y-inc) only -- both on diagonal k-1, both final when diagonal k starts -- so the
+ * pixels of a diagonal may run in any order or in parallel.  x-predecessor first, then y-predecessor against the updated minimum
+ * (:198-212); the first sweep row has only the former (:178-186), the first column only the latter (:189-195). */
+static void spatial_raster_wavefront(csor_pm *pm, int cur_iter, const csor_pc *pc, const csor_pm_opts *o) {
+  const int wid = pm->wid, hei = pm->hei;
+  const int inc = (cur_iter % 2 == 0) ? 1 : -1;
+  for (int v = 0; v < 2; ++v) {
+    plane_t *P = pm->plane[v];
+    for (int k = 1; k <= wid + hei - 2; ++k) {
+      const int ys_lo = k - (wid - 1) > 0 ? k - (wid - 1) : 0, ys_hi = k < hei - 1 ? k : hei - 1;
+      long long ev = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : ev)
+      for (int ys = ys_lo; ys <= ys_hi; ++ys) {
+        const int xs = k - ys;
+        const int x = inc > 0 ? xs : wid - 1 - xs, y = inc > 0 ? ys : hei - 1 - ys;
+        if (xs > 0) {
+          plane_t nx_plane = P[(size_t)y * wid + (x - inc)];
+          try_plane(pm, pc, o, v, x, y, &nx_plane);
+          ++ev;
+        }
+        if (ys > 0) {
+          plane_t ny_plane = P[(size_t)(y - inc) * wid + x];
+          try_plane(pm, pc, o, v, x, y, &ny_plane);
+          ++ev;
+        }
+      }
+      pm->evals += ev;
+    }
+  }
+}
+
 /* Device fast-path schedule (DESIGN.md "red-black"): per round two half-steps; in half-step hs
  * the pixels with ((x+y)&1) == ((hs + cur_iter)&1) test the planes of their in-image neighbours
  * in the order (x-inc,y), (x,y-inc), (x+inc,y), (x,y+inc) [first 2 only if rb_neighbours==2],
@@ -939,6 +971,7 @@ void csor_pm_spatial(csor_pm *pm, int cur_iter, const csor_pc *pc, const csor_pm
   apply_threads(o ? o : &k_default_opts);
   if (!o) o = &k_default_opts;
   if (o->schedule == CSOR_SCHED_REDBLACK) spatial_redblack(pm, cur_iter, pc, o);
+  else if (o->wavefront) spatial_raster_wavefront(pm, cur_iter, pc, o);
   else spatial_raster(pm, cur_iter, pc, o);
 }
 

@@ -127,6 +127,10 @@ typedef struct {
   int rb_rounds;     /* red-black rounds per iteration (>=1); ignored for raster */
   int rb_neighbours; /* 2 or 4 */
   int threads;       /* OpenMP threads for init/refinement rows (0 = default) */
+  int wavefront;     /* 0: the raster sweep is the reference's serial double loop (cs_patchmatch.cc:163-216).  1: the same sweep walked
+                        anti-diagonal by anti-diagonal with the pixels of a diagonal in parallel -- pixel (x,y) reads only (x-inc,y) and
+                        (x,y-inc), both on the previous diagonal, so the result is the serial loop's bit for bit (asserted by
+                        tests/test_oracle_primitives.py); a speed knob for the whole-KITTI-pair parity test, nothing else */
 } csor_pm_opts;
 
 csor_pm *csor_pm_create(const uint8_t *l_bgr, const uint8_t *r_bgr, int w, int h,

@@ -52,7 +52,7 @@ def build(force=False):
 
 class PmOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_int), ("schedule", C.c_int), ("sum_order", C.c_int),
-                ("rb_rounds", C.c_int), ("rb_neighbours", C.c_int), ("threads", C.c_int)]
+                ("rb_rounds", C.c_int), ("rb_neighbours", C.c_int), ("threads", C.c_int), ("wavefront", C.c_int)]
 
 
 _lib = None
@@ -231,10 +231,12 @@ class PatchMatch:
 
     @staticmethod
     def opts(seed=12345, rng_mode=RNG_PER_PIXEL, schedule=SCHED_RASTER, sum_order=SUM_SERIAL, rb_rounds=1,
-             rb_neighbours=4, threads=0):
+             rb_neighbours=4, threads=0, wavefront=False):
+        """wavefront: the raster sweep walked anti-diagonal by anti-diagonal in parallel (identical results, a speed knob for the
+        whole-KITTI-pair test); the default is the reference's serial double loop"""
         if not threads:  # OpenMP's own default is every visible CPU, whatever the container may use
             threads = effective_cpus()
-        return PmOpts(seed, rng_mode, schedule, sum_order, rb_rounds, rb_neighbours, threads)
+        return PmOpts(seed, rng_mode, schedule, sum_order, rb_rounds, rb_neighbours, threads, int(bool(wavefront)))
 
     def run(self, iters, pc, use_pp=False, **kw):
         o = self.opts(**kw)

@@ -1,4 +1,7 @@
-"""One rank of tests/test_gpu_batch.py::test_run_batch_two_ranks_one_gpu: gloo process group, compute on cuda:0."""
+"""One rank of tests/test_gpu_batch.py.
+  default (CSPM_BATCH_BACKEND unset / "gloo"): test_run_batch_two_ranks_one_gpu -- gloo process group, compute on cuda:0;
+  CSPM_BATCH_BACKEND=nccl: test_run_batch_over_rccl_world1 -- an RCCL process group on cuda:0 (world size 1 on a one-GPU box),
+  device tensors end to end, run_batch(force_collectives=True)."""
 import os
 import sys
 
@@ -15,6 +18,21 @@ from test_gpu_batch import PARAMS  # noqa: E402
 def main():
     out_dir = sys.argv[1]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("CSPM_BATCH_BACKEND", "gloo")
+    if backend == "nccl":
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        rank = dist.get_rank()
+        fn = batch.HipPairFn(dev.index, in_flight=2)
+        pairs = torch.from_numpy(np.load(os.path.join(out_dir, "pairs.npy"))).to(dev) if rank == 0 else None  # the batch is resident in HBM
+        got = batch.run_batch(pairs, PARAMS if rank == 0 else None, fn, device=str(dev), dist=dist, chunk_pairs=2, force_collectives=True)
+        torch.cuda.synchronize()
+        fn.close()
+        if rank == 0:
+            np.save(os.path.join(out_dir, "out.npy"), got.cpu().numpy())
+        dist.destroy_process_group()
+        return
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     torch.cuda.init()

@@ -77,3 +77,21 @@ def test_run_batch_two_ranks_one_gpu(gpu_ctx, tmp_path):
     subprocess.run(cmd, check=True, env=env, timeout=600)
     got = np.load(tmp_path / "out.npy")
     np.testing.assert_array_equal(got, _direct(gpu_ctx, pairs))
+
+
+def test_run_batch_over_rccl_world1(gpu_ctx, tmp_path):
+    """The RCCL code path itself (torch.distributed backend "nccl"), on the one GPU a test box has: a process group of world
+    size 1 on cuda:0 and run_batch(force_collectives=True) -- the parameter broadcast, the chunked asynchronous scatter of views
+    of the device-resident batch (rounds of 2 pairs, a ragged last round), HipPairFn with 2 contexts in flight ordered against
+    the collectives' stream, and the gather of the device maps all execute as RCCL kernels.  A separate process, so that the
+    suite's own process never owns a process group.  Maps == the direct C-ABI path."""
+    pairs = _pairs(5)
+    np.save(tmp_path / "pairs.npy", pairs)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", CSPM_BATCH_BACKEND="nccl")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "batch_rank.py"), str(tmp_path)], check=True, env=env, timeout=600)
+    got = np.load(tmp_path / "out.npy")
+    np.testing.assert_array_equal(got, _direct(gpu_ctx, pairs))

@@ -57,6 +57,30 @@ def test_grd_build_cv_host_boundary(small_pair):
         np.testing.assert_array_equal(got, want)
 
 
+def test_reference_cells_at_the_pyramid_levels(gpu_ctx, odd_pair):
+    """The volumes the device keeps (cspm_get_cost_slab, CSPM_OPT_GRD_VOLUMES, max_cost) hold the DEVICE cells -- myCostGrd with its last
+    multiply-add contracted -- and differ from GrdCC::buildCV's by <= 1 ulp.  The reference's own cells stay reachable at every
+    pyramid level through the CCMethod::buildCV boundary: the level images the device built (pyrDown chain) fed to
+    cspm_grd_build_cv_host give the oracle's reference-arithmetic volumes (pc.volume) bit for bit, and the device cells of the same
+    level (pc.volume_dev == cspm_get_cost_slab) sit within one ulp of them."""
+    import ctypes as C
+    import crossscalepatchmatch_amd as cs
+    L = cs.load_library()
+    pc = _build(gpu_ctx, odd_pair, 3, 0.3)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for s in range(3):
+        w, h, D = gpu_ctx.level_dims(s)
+        rgb = [np.ascontiguousarray(gpu_ctx.level_image(v, s)[..., ::-1].astype(np.float64)) for v in (0, 1)]  # CV_64FC3 RGB, as PreCSPC hands them on (pre_cs_pc.cc:61-64)
+        for right in (0, 1):
+            got = np.zeros((D + 1, h, w))
+            assert L.cspm_grd_build_cv_host(0, dp(rgb[0]), dp(rgb[1]), w, h, D + 1, right, dp(got)) == 0, L.cspm_last_error(None)
+            ref = pc.volume(right, s)
+            np.testing.assert_array_equal(got, ref, err_msg=f"reference cells, level {s}, view {right}")
+            dev = gpu_ctx.cost_volume(right, s)
+            np.testing.assert_array_equal(dev, pc.volume_dev(right, s))
+            assert np.max(np.abs(dev - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))) <= 1.0
+
+
 @pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
 @pytest.mark.parametrize("pairname", ["small_pair", "odd_pair"])
 @pytest.mark.parametrize("name,scale_num,lam", CASES)

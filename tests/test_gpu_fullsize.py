@@ -159,22 +159,85 @@ def test_north_star_bar_full_c1_c2(gpu_ctx, name):
         assert within >= 0.995, (name, v, within, float(d.max()))
 
 
-def test_c5_full_resolution_runs(gpu_ctx):
-    """BASELINE.json configs[4]: 3000x2000, max_dis=256, cross-scale, use_pp=true.  f64 volumes would be 28 GB; the
-    fused cost needs ~0.3 GB.  One iteration + post-processing; self-consistency of stored costs."""
+def test_c5_full_resolution_three_iterations_and_postprocessing(gpu_ctx):
+    """BASELINE.json configs[4]: 3000x2000, max_dis=256, cross-scale, use_pp=true, 3 iterations.  f64 volumes would be 28 GB; the
+    fused cost needs ~0.3 GB.  The oracle cannot run PatchMatch at this size, but PostProcessing (cs_patchmatch.cc:508-588) is cheap
+    on the CPU: the GPU's OWN final plane field is handed to the oracle, which runs PlaneToDisp + LeftRightCheck + FillInvalid +
+    WeightedMedian on it -- the 8-bit maps of cspm_postprocess must be identical at full resolution (rows wider than one scan
+    block of k_fill_rows, > 64 K inconsistent pixels for k_weighted_median's work list).  Plus self-consistency of stored costs."""
     cfg, l, r, gl, _ = synth.make_config("C5")
     gpu_ctx.set_images(l, r)
     gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
     assert gpu_ctx.level_dims(4) == (188, 125, 16)
-    gpu_ctx.patchmatch(1, seed=7, schedule=0)
-    npar, cost = gpu_ctx.get_planes(0)
+    gpu_ctx.patchmatch(3, seed=7, schedule=0)
+    fields = [gpu_ctx.get_planes(v) for v in (0, 1)]
+    npar, cost = fields[0]
     rng = np.random.default_rng(9)
     ys, xs = rng.integers(0, cfg["h"], 2000), rng.integers(0, cfg["w"], 2000)
     got = gpu_ctx.plane_cost_batch(0, np.stack([xs, ys], 1), npar[ys, xs])
     np.testing.assert_array_equal(got, cost[ys, xs])
+    raw = [gpu_ctx.disparity_u8(v, cfg["dis_scale"]) for v in (0, 1)]
     lo, ro = gpu_ctx.postprocess(cfg["dis_scale"])
-    assert lo.shape == (2000, 3000) and lo.max() <= 255
+    assert lo.shape == (2000, 3000)
+    pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
+    for v in (0, 1):
+        P = pm.planes(v)  # 9 doubles per pixel: norm, point, param -- PlaneToDisp reads the parameters only
+        P[..., 0:3] = fields[v][0][..., 0:3]
+        P[..., 6:9] = fields[v][0][..., 3:6]
+    pm.plane_to_disp()
+    for v in (0, 1):
+        np.testing.assert_array_equal(raw[v], pm.dis(v), err_msg=f"PlaneToDisp, view {v}")
+    pm.postprocess()
+    np.testing.assert_array_equal(lo, pm.dis(0), err_msg="post-processed left map")
+    np.testing.assert_array_equal(ro, pm.dis(1), err_msg="post-processed right map")
+    changed = float(np.mean(lo != raw[0]))
+    assert changed > 0.005 and int(np.sum(lo != raw[0])) > 65536, changed  # not vacuous: far more than 64 K pixels were rewritten
+    assert synth.bad_fraction(lo.astype(np.float64) / cfg["dis_scale"], gl, 2.0) < 0.2
     gpu_ctx.set_images(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8))  # release the big buffers
+
+
+def test_c3_whole_pair_bit_exact(gpu_ctx, c3):
+    """The headline configuration end to end (BASELINE.json configs[2]: 1242x375, max_dis 128, GRD, 5 levels, lambda 0.3, 3 iterations,
+    raster sweeps): one WHOLE pair through the HIP path and through the CPU oracle in the same device order -- all 2 x 465 750
+    planes, every stored cost, both 8-bit maps and the unquantised disparities identical.  ~1.9e11 window taps on the host: three to
+    five minutes on the GPU box's 16 usable cores (the oracle's raster sweep runs as an anti-diagonal wavefront here, which
+    tests/test_oracle_primitives.py shows equal to its serial loop)."""
+    cfg, l, r, gl, _ = c3
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    gpu_ctx.patchmatch(3, seed=12345, schedule=0)
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
+    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE, wavefront=True)
+    for v in (0, 1):
+        npar, cost = gpu_ctx.get_planes(v)
+        P = pm.planes(v)
+        np.testing.assert_array_equal(npar[..., :3], P[..., 0:3], err_msg=f"normals, view {v}")
+        np.testing.assert_array_equal(npar[..., 3:], P[..., 6:9], err_msg=f"plane parameters, view {v}")
+        np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"stored costs, view {v}")
+        np.testing.assert_array_equal(gpu_ctx.disparity_u8(v, cfg["dis_scale"]), pm.dis(v), err_msg=f"8-bit map, view {v}")
+        np.testing.assert_array_equal(gpu_ctx.disparity_f64(v), pm.disp_f64(v))
+    assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.2
+
+
+def test_north_star_bar_c3_crop_reference_order(gpu_ctx, c3):
+    """The north-star bar on the headline configuration's content: a centred 320-column crop of the C3 pair at full height and full
+    disparity range (1242x375 -> 320x375, max_dis 128, 5 levels; a CROP, because the reference order keeps the raster sweep serial
+    and the whole pair would take four minutes more) on the GPU against the CPU oracle in the REFERENCE order (serial raster sweep,
+    serial window sum, no FMA), identical inputs and random numbers: >= 99.5 % of the pixels of both views within 0.5 px."""
+    cfg, l, r, _, _ = c3
+    x0 = (cfg["w"] - 320) // 2
+    lc, rc = np.ascontiguousarray(l[:, x0:x0 + 320]), np.ascontiguousarray(r[:, x0:x0 + 320])
+    gpu_ctx.set_images(lc, rc)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    gpu_ctx.patchmatch(3, seed=12345, schedule=0)
+    pc = po.PlaneCost(lc, rc, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(lc, rc, cfg["max_dis"], cfg["dis_scale"])
+    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+    for v in (0, 1):
+        d = np.abs(gpu_ctx.disparity_f64(v) - pm.disp_f64(v))
+        within = float(np.mean(d <= 0.5))
+        assert within >= 0.995, (v, within, float(d.max()))
 
 
 def test_c3_persistent_sweep_vs_per_diagonal_launches(gpu_ctx, c3):

@@ -11,9 +11,15 @@ pytestmark = pytest.mark.gpu
 MODES = [("ss", 0, 0.0), ("cs", 5, 0.3)]
 
 
-def _setup(ctx, pair, scale_num, lam, volumes=False):
+def _setup(ctx, pair, scale_num, lam, volumes=False, sweep_pairs=False):
+    """volumes: False = fused cells everywhere (the default build), "pairs" = fused cells + paired-cell volumes for the raster
+    sweep (CSPM_OPT_SWEEP_PAIRS), True = materialised f64 volumes"""
+    if volumes == "pairs":
+        volumes, sweep_pairs = False, True
     ctx.set_images(pair["l"], pair["r"])
-    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam, volumes=volumes)
+    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam, volumes=volumes, sweep_pairs=sweep_pairs)
+    from crossscalepatchmatch_amd import capi
+    assert ctx.get_option(capi.OPT_SWEEP_PAIRS_ACTIVE) == int(bool(sweep_pairs) and not volumes)
     pc = po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], 35, scale_num, lam)
     pm = po.PatchMatch(pair["l"], pair["r"], pair["max_dis"], 4)
     return pc, pm
@@ -28,7 +34,7 @@ def _assert_state_equal(ctx, pm, what):
         np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"{what}: min_cost, view {v}")
 
 
-@pytest.mark.parametrize("volumes", [False, True], ids=["fused", "volumes"])
+@pytest.mark.parametrize("volumes", [False, "pairs", True], ids=["fused", "sweep_pairs", "volumes"])
 @pytest.mark.parametrize("name,scale_num,lam", MODES)
 @pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
 def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched, volumes):
@@ -48,11 +54,14 @@ def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched, volume
 
 @pytest.mark.parametrize("pairname", ["mid_pair", "odd_pair"])
 @pytest.mark.parametrize("name,scale_num,lam", MODES)
-@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
+@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER, "raster_pairs"])
 def test_whole_pipeline_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam, sched):
     """T3/T4: PatchMatch(3, plane_cost, false) + PlaneToDisp."""
     pair = request.getfixturevalue(pairname)
-    pc, pm = _setup(gpu_ctx, pair, scale_num, lam)
+    src = False
+    if sched == "raster_pairs":
+        sched, src = po.SCHED_RASTER, "pairs"
+    pc, pm = _setup(gpu_ctx, pair, scale_num, lam, src)
     pm.run(3, pc, False, seed=4242, schedule=sched, sum_order=po.SUM_DEVICE, rb_rounds=1, rb_neighbours=4)
     gpu_ctx.patchmatch(3, seed=4242, schedule=sched, rb_rounds=1, rb_neighbours=4, early_exit=1)
     _assert_state_equal(gpu_ctx, pm, "final")
@@ -385,6 +394,97 @@ def test_sweep_timeout_falls_back_to_per_diagonal_launches(gpu_ctx, mid_pair):
         np.testing.assert_array_equal(ctx.get_planes(0)[1], want[0][1])
     finally:
         ctx.close()
+
+
+def test_sweep_timeout_behind_asynchronous_outputs(gpu_ctx, mid_pair):
+    """The maps a caller asks for BEHIND an asynchronous run (cspm_get_disparity_u8, cspm_disparity_u8_device,
+    cspm_postprocess_device, batch.HipPairFn with one pair per context) must come from the planes of the REPEATED run when the
+    persistent sweep timed out -- never from the aborted sweep's planes with CSPM_OK."""
+    import torch
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import batch, capi
+    dev = torch.device("cuda", 0)
+    h, w, D = mid_pair["h"], mid_pair["w"], mid_pair["max_dis"]
+    ctx = cs.StereoContext(0)
+    try:
+        ctx.set_images(mid_pair["l"], mid_pair["r"])
+        ctx.build_cost_grd(D, 35, 5, 0.3)
+        ctx.patchmatch(2, seed=9, schedule=0)
+        want_u8 = [ctx.disparity_u8(v, 4) for v in (0, 1)]
+        want_pp = ctx.postprocess(4)
+        ctx.set_option(capi.OPT_SWEEP_TIMEOUT_MS, 0)
+        # host getter: the check comes before PlaneToDisp
+        ctx.patchmatch(2, seed=9, schedule=0)
+        np.testing.assert_array_equal(ctx.disparity_u8(0, 4), want_u8[0])
+        assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 1
+        # device-resident map enqueued behind the run, then a synchronising call
+        outs = [torch.zeros((h, w), dtype=torch.uint8, device=dev) for _ in range(2)]
+        ctx.patchmatch(2, seed=9, schedule=0)
+        for v in (0, 1):
+            ctx.disparity_u8_device(v, 4, outs[v].data_ptr())
+        ctx.synchronize()
+        assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 2
+        for v in (0, 1):
+            np.testing.assert_array_equal(outs[v].cpu().numpy(), want_u8[v])
+        # post-processed maps likewise
+        ctx.patchmatch(2, seed=9, schedule=0)
+        ctx.postprocess_device(4, outs[0].data_ptr(), outs[1].data_ptr())
+        ctx.synchronize()
+        assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 3
+        for v in (0, 1):
+            np.testing.assert_array_equal(outs[v].cpu().numpy(), want_pp[v])
+    finally:
+        ctx.close()
+    # the batch driver: one pair per context, every context's sweep times out, finalize() repeats each run and its maps
+    fn = batch.HipPairFn(0, in_flight=2)
+    try:
+        for c in fn.ctxs:
+            c.set_option(capi.OPT_SWEEP_TIMEOUT_MS, 0)
+        pairs = torch.stack([torch.stack([torch.from_numpy(mid_pair["l"]), torch.from_numpy(mid_pair["r"])])] * 2).to(dev)
+        params = dict(w=w, h=h, max_dis=D, dis_scale=4, scale_num=5, reg_lambda=0.3, iters=2, seed=9, schedule=0, use_pp=0, cc=batch.CC_CODES["GRD"])
+        maps = batch.run_batch(pairs, params, fn, device="cuda:0", dist=None)  # pair k runs with seed 9 + k
+        assert sum(c.get_option(capi.OPT_SWEEP_FALLBACKS) for c in fn.ctxs) == 2
+        gpu_ctx.set_images(mid_pair["l"], mid_pair["r"])
+        gpu_ctx.build_cost_grd(D, 35, 5, 0.3)
+        for k in range(2):
+            gpu_ctx.patchmatch(2, seed=9 + k, schedule=0)
+            for v in (0, 1):
+                np.testing.assert_array_equal(maps[k, v].cpu().numpy(), gpu_ctx.disparity_u8(v, 4))
+    finally:
+        fn.close()
+
+
+def test_sweep_row_bands_and_paired_cells(gpu_ctx):
+    """Two options of the persistent sweep that change who evaluates what and where the cells come from, never the result:
+    CSPM_SWEEP_BANDS (one claim queue per row band / XCD) and CSPM_OPT_SWEEP_PAIRS (paired-cell volumes) -- alone and together,
+    on an image with more rows than bands and several workgroups per band: identical planes and costs."""
+    import os
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import capi, synth
+    w, h, D = 200, 150, 24
+    l, r, _, _ = synth.make_pair(w, h, D, regions=4, seed=404)
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(D, 35, 5, 0.3)
+    gpu_ctx.patchmatch(2, seed=3, schedule=0)
+    want = [gpu_ctx.get_planes(v) for v in (0, 1)]
+    for bands, pairs in ((8, False), (3, True), (8, True), (1, True)):
+        os.environ["CSPM_SWEEP_BANDS"] = str(bands)
+        try:
+            ctx = cs.StereoContext(0)
+        finally:
+            del os.environ["CSPM_SWEEP_BANDS"]
+        try:
+            ctx.set_images(l, r)
+            ctx.build_cost_grd(D, 35, 5, 0.3, sweep_pairs=pairs)
+            assert ctx.get_option(capi.OPT_SWEEP_PAIRS_ACTIVE) == int(pairs)
+            ctx.patchmatch(2, seed=3, schedule=0)
+            for v in (0, 1):
+                npar, cost = ctx.get_planes(v)
+                np.testing.assert_array_equal(npar, want[v][0], err_msg=f"bands {bands} pairs {pairs} view {v}")
+                np.testing.assert_array_equal(cost, want[v][1], err_msg=f"bands {bands} pairs {pairs} view {v}")
+            assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 0
+        finally:
+            ctx.close()
 
 
 def test_new_cost_object_withdraws_the_stored_costs(gpu_ctx, small_pair):

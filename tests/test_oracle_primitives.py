@@ -126,3 +126,20 @@ def test_init_normals_are_unit_and_isotropic(small_pair):
     z = P[..., 5]
     assert z.min() >= 1e-8 and z.max() < small_pair["max_dis"]
     np.testing.assert_array_equal(P[..., 3], np.tile(np.arange(small_pair["w"]), (small_pair["h"], 1)))
+
+
+@pytest.mark.parametrize("scale_num,lam,sum_order", [(0, 0.0, po.SUM_SERIAL), (3, 0.3, po.SUM_DEVICE)])
+def test_wavefront_sweep_is_the_serial_sweep(odd_pair, scale_num, lam, sum_order):
+    """csor_pm_opts.wavefront walks the raster sweep anti-diagonal by anti-diagonal with OpenMP over a diagonal's pixels (the speed
+    knob of the whole-KITTI-pair GPU test): planes, costs and evaluation counts equal the reference's serial double loop
+    (cs_patchmatch.cc:163-216) in both sweep directions, over several iterations."""
+    l, r, D = odd_pair["l"], odd_pair["r"], odd_pair["max_dis"]
+    pc = po.PlaneCost(l, r, D, 9, scale_num, lam)
+    out = []
+    for wavefront in (False, True):
+        pm = po.PatchMatch(l, r, D, 4)
+        pm.run(3, pc, False, seed=77, schedule=po.SCHED_RASTER, sum_order=sum_order, threads=4, wavefront=wavefront)
+        out.append((pm.planes(0).copy(), pm.planes(1).copy(), pm.min_cost(0).copy(), pm.min_cost(1).copy(), pm.evals()))
+    for a, b in zip(out[0][:4], out[1][:4]):
+        np.testing.assert_array_equal(a, b)
+    assert out[0][4] == out[1][4]

@@ -19,6 +19,7 @@ python tools/pmc_to_json.py gpurun_out/$TAG k_spatial_sweep gpurun_out/$TAG/swee
 # 1. the default bench line (three pairs in flight, CPU baseline) and the one-pair-at-a-time line -- after the counter passes, so
 #    that the line quotes the counters of THIS build (profiles/refine_pmc.json is refused when its source hash differs)
 cp $O/refine_pmc.json profiles/refine_pmc.json
+cp $O/sweep_pmc.json profiles/sweep_pmc.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --in-flight 1 --no-cpu-baseline > $O/bench_inflight1.json 2> /dev/null
 # 5. the other BASELINE.json configs (3 pairs in flight; C5 includes post-processing; C4 goes through batch.run_batch) -- for reference, not the headline

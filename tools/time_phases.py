@@ -23,7 +23,7 @@ if kind == "cen":
 elif kind == "img":
     ctx.build_cost_img(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
 else:
-    ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=kind == "grdvol")
+    ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], volumes=kind == "grdvol", sweep_pairs=os.environ.get("CSPM_TP_PAIRS", "0") != "0")
 ctx.patchmatch(1, seed=12345)  # warm-up
 ctx.synchronize()
 ctx.enable_timing(True)
