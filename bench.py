@@ -134,6 +134,12 @@ def cpu_baseline(device_index=0):
 
 
 def main():
+    # ONE JSON line on stdout, nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL prints a
+    # five-line version banner there when a communicator is created).  Keep the real stdout for the result line and point fd 1 at
+    # stderr for everything else, in this process and in whatever it loads.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -176,7 +182,7 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(subprocess.call(cmd, stdout=result_out))  # the ranks inherit the real stdout; rank 0 writes the line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -436,7 +442,8 @@ def main():
             last = ctxs[(args.steps - 1) % nfl]
             out["bad2_vs_gt_left"] = synth.bad_fraction(last.disparity_f64(0), gl, 2.0)
         out["distinct_pairs"] = npairs
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if pair_fn is not None:
         pair_fn.close()
     else:
