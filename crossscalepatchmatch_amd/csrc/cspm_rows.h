@@ -43,6 +43,9 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_INIT_MINW
 #define CSPM_INIT_MINW CSPM_ROW_MINW
 #endif
+#ifndef CSPM_ROW_EXIT
+#define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
+#endif
 #ifndef CSPM_CELL_MODE
 #define CSPM_CELL_MODE 1  // coarse levels of the fused GRD cost: per-row cell and weight tables (cell mode below); 0 = always the general taps
 #endif
@@ -490,7 +493,7 @@ __device__ __forceinline__ RowCtx make_row_ctx(unsigned char *smem, int y, int c
 #endif
 template <int SRC, int VIEW>
 __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, const RowCtx &ctx, int s, int cx, int cy, double a, double b,
-                                             double c) {
+                                             double c, bool exit_on, double need, bool dead_in) {
   constexpr int E = elem_size<SRC>();
   const int lane = ctx.lane;
   const Level &L = cd.lv[s];
@@ -542,6 +545,20 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
   RowTree tree;
   const int dy_lo = max(0, A.half - cy), dy_hi = min(A.n - 1, L.H - 1 - cy + A.half);
   for (int dy = 0; dy < dy_lo; ++dy) tree.push(dy, 0.0);
+  // Row-granular early exit (result-preserving, only with the early-exit licence): `need` is what the level sum must reach for
+  // the lane's total to be >= its threshold, with a 2^-40 margin over every rounding on the way (eval_rows_view).  Row totals
+  // are >= 0, so a running sum of completed rows that has reached it proves the rejection; once that holds in all 64 lanes the
+  // wave abandons the level -- a rejected candidate's cost is never stored.  Returns +inf then.
+  double partial = 0.0;
+  auto all_rejected = [&](double Rsum) -> bool {
+#if CSPM_ROW_EXIT
+    if (!exit_on) return false;
+    partial = partial + Rsum;
+    return __builtin_amdgcn_ballot_w64(!(dead_in | (partial >= need))) == 0ull;
+#else
+    return false;
+#endif
+  };
   if constexpr (SRC == kSrcGrd) {
     // cell mode: does the row's cell table + weight table + ONE compact strip set fit this wave's LDS?
     const int ncent = cmax - cmin + 1, NQ = o_len;
@@ -653,6 +670,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const double Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? cell_row_taps<true>(A, C, a, rowterm, qx0_d)
                                                                        : cell_row_taps<false>(A, C, a, rowterm, qx0_d);
         tree.push(dy, Rsum);
+        if (all_rejected(Rsum)) { dma_wait(); return __builtin_inf(); }
       }
       return tree.total(dy_hi + 1);
     }
@@ -707,6 +725,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           Rsum = row_taps<SRC, VIEW, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
         }
         tree.push(dy, Rsum);
+        if (all_rejected(Rsum)) { dma_wait(); return __builtin_inf(); }
         par ^= 1;
       }
       return tree.total(dy_hi + 1);
@@ -789,6 +808,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       Rsum = row_taps<SRC, VIEW, true, false>(A, lut, R, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
     }
     tree.push(dy, Rsum);
+    if (all_rejected(Rsum)) return __builtin_inf();
     if (staged && more) {
       wave_lds_fence();
       commit();
@@ -839,7 +859,12 @@ __device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut
       }
       plane_param(p.nx, p.ny, p.nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);
     }
-    const double sc = level_rows<SRC, VIEW>(cd, lut, ctx, s, cur_x, cur_y, a, b, c);
+    // what this level's sum must reach to prove cost >= thresh: (thresh - cost so far) / weight, plus a 2^-40 margin that covers
+    // the roundings of the division, of the row-tree sum against a running sum, of the product and of the final addition
+    const double lw = CS ? cd.lv[s].wgt : 1.0;
+    const double need = (thresh - cost) / lw * (1.0 + 0x1p-40);  // weight 0 (lambda = 0): +inf / NaN, never reached
+    const double sc = level_rows<SRC, VIEW>(cd, lut, ctx, s, cur_x, cur_y, a, b, c, use_thresh, need, dead);
+    if (use_thresh && __builtin_amdgcn_ballot_w64(!__builtin_isinf(sc)) == 0ull) { dead = true; break; }  // every lane proven rejected in mid-level (wave-uniform)
     if (CS) cost += sc * cd.lv[s].wgt;  // :182
     else cost = sc;
     if (use_thresh) {
