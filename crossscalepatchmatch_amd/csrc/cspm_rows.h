@@ -46,6 +46,9 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_ROW_EXIT
 #define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
 #endif
+#ifndef CSPM_RANGE_MODE
+#define CSPM_RANGE_MODE 1  // cell mode with range-restricted tables on the levels whose full tables do not fit (0: general taps there)
+#endif
 #ifndef CSPM_CELL_MODE
 #define CSPM_CELL_MODE 1  // coarse levels of the fused GRD cost: per-row cell and weight tables (cell mode below); 0 = always the general taps
 #endif
@@ -55,6 +58,10 @@ constexpr int kRowBlock = kRowWaves * kWave;
 // window rows (per wave) whose 64 lanes all take the interpolation branch, bucketed by the number of integer disparities the
 // wave touches on that row (<= 4, 8, 16, 32, more); bucket 5 = rows with some lane outside [1, D); bucket 6 = unstaged rows
 __device__ unsigned long long g_rowstat[16 * 8 * 8];
+// the same slots and levels for the range-restricted cell mode, per level pass of a wave: 0 passes that got to the range test,
+// 1 some lane not interpolating everywhere, 2 range tables with the weight table, 3 without, 4 too many disparities for the LDS,
+// 5 sum of ND over the passes that took range mode, 6 sum of ND over the passes of bucket 4, 7 full cell mode
+__device__ unsigned long long g_rangestat[16 * 8 * 8];
 #endif
 
 // Two wave-private LDS strips per window row (sized by strip_capacity / own_capacity, carved from the launch's dynamic LDS):
@@ -401,17 +408,26 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
 // Used where it fits the wave's LDS (levels 3 and 4 of a KITTI pyramid); measured in DESIGN.md section 7.
 // ------------------------------------------------------------------------------------------------
 struct CellRow {
-  int adr_c;   // lane: LDS address of cells[d = 0][q0] of the lane's window column 0 (biased one disparity down: f indexes d = f)
+  int adr_c;   // lane: LDS address of the table row of disparity 0 at the lane's window column 0 (a virtual row: f indexes it)
   int stride;  // bytes between consecutive disparities: NQ * 8
-  int adr_w;   // lane: LDS address of wgts[centre of the lane][0]
+  int adr_w;   // lane: LDS address of wgts[centre of the lane][0]                                (WTAB)
   int adr_w2, adr_w3, adr_w4;  // == adr_w, opaque to the compiler: the weight reads of a batch must not be merged into ds_read2_b64 (half rate)
+  int adr_p;   // lane: LDS address of the own view's colour of the lane's window column 0        (!WTAB: guide weights on the fly)
+  uint32_t Ip; // the centre's colour                                                             (!WTAB)
 };
-template <bool ALLV, int J0, int J1>
-__device__ __forceinline__ void cell_batch(const RowLevel &A, const CellRow &C, int adr_c, int adr_c1, int adr_w, int g8, double pa, double Gg,
-                                           double S[kRowMod]) {
+// WTAB: the guide weights come from the per-row table wgts[centre][column]; otherwise every tap forms its own (own colour from the
+// strip set, |dI| -> exp table: :161-164) -- levels with too many centres for the table, rows inside the image only
+template <bool ALLV, bool WTAB, int J0, int J1>
+__device__ __forceinline__ void cell_batch(const RowLevel &A, const Luts &lut, const CellRow &C, int adr_c, int adr_c1, int adr_w, int adr_p, int g8,
+                                           double pa, double Gg, double S[kRowMod]) {
   constexpr int N = J1 - J0;
   double c0[N], c1[N], w[N], fr[N];
   bool valid[N];
+  uint32_t pq[N];
+  if constexpr (!WTAB) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) pq[k] = lds_ld<uint32_t>(adr_p + (J0 + k) * 4);
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int j = J0 + k;
@@ -424,7 +440,11 @@ __device__ __forceinline__ void cell_batch(const RowLevel &A, const CellRow &C, 
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(d.f), "s"(C.stride), "v"(adr_c1));
     c0[k] = lds_ld<double>(a0 + j * 8);
     c1[k] = lds_ld<double>(a1 + j * 8);
-    w[k] = lds_ld<double>((k == 0 ? adr_w : k == 1 ? C.adr_w2 : k == 2 ? C.adr_w3 : C.adr_w4) + g8 + j * 8);
+    if constexpr (WTAB) w[k] = lds_ld<double>((k == 0 ? adr_w : k == 1 ? C.adr_w2 : k == 2 ? C.adr_w3 : C.adr_w4) + g8 + j * 8);
+  }
+  if constexpr (!WTAB) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) w[k] = lut.w[(int)__builtin_amdgcn_sad_u8(C.Ip, pq[k], 0u)];
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -434,26 +454,27 @@ __device__ __forceinline__ void cell_batch(const RowLevel &A, const CellRow &C, 
     S[J0 + k] = __builtin_fma(w[k], t, S[J0 + k]);
   }
 }
-template <bool ALLV, int CNT>
-__device__ __forceinline__ void cell_group(const RowLevel &A, const CellRow &C, int g0, double pa, double rowterm, double &qxg_d, double S[kRowMod]) {
+template <bool ALLV, bool WTAB, int CNT>
+__device__ __forceinline__ void cell_group(const RowLevel &A, const Luts &lut, const CellRow &C, int g0, double pa, double rowterm, double &qxg_d,
+                                           double S[kRowMod]) {
   const double Gg = group_disp(pa, qxg_d, rowterm);
   qxg_d += (double)kRowMod;
-  const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w;
+  const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w, adr_p = C.adr_p + g0 * 4;
   constexpr int SUB = 4;
-  cell_batch<ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, C, adr_c, adr_c1, adr_w, g8, pa, Gg, S);
-  if constexpr (CNT > SUB) cell_batch<ALLV, SUB, CNT>(A, C, adr_c, adr_c1, adr_w, g8, pa, Gg, S);
+  cell_batch<ALLV, WTAB, 0, (CNT < SUB ? CNT : SUB)>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
+  if constexpr (CNT > SUB) cell_batch<ALLV, WTAB, SUB, CNT>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
 }
-template <bool ALLV>
-__device__ __forceinline__ double cell_row_taps(const RowLevel &A, const CellRow &C, double pa, double rowterm, double qx0_d) {
+template <bool ALLV, bool WTAB>
+__device__ __forceinline__ double cell_row_taps(const RowLevel &A, const Luts &lut, const CellRow &C, double pa, double rowterm, double qx0_d) {
   double S[kRowMod];
 #pragma unroll
   for (int j = 0; j < kRowMod; ++j) S[j] = 0.0;
   double qx_d = qx0_d;
   const int full = A.n / kRowMod * kRowMod;
   int g0 = 0;
-  for (; g0 < full; g0 += kRowMod) cell_group<ALLV, kRowMod>(A, C, g0, pa, rowterm, qx_d, S);
+  for (; g0 < full; g0 += kRowMod) cell_group<ALLV, WTAB, kRowMod>(A, lut, C, g0, pa, rowterm, qx_d, S);
   switch (A.n - full) {
-#define CSPM_TAIL(K) case K: cell_group<ALLV, K>(A, C, g0, pa, rowterm, qx_d, S); break;
+#define CSPM_TAIL(K) case K: cell_group<ALLV, WTAB, K>(A, lut, C, g0, pa, rowterm, qx_d, S); break;
     CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
 #undef CSPM_TAIL
     default: break;
@@ -560,68 +581,128 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
 #endif
   };
   if constexpr (SRC == kSrcGrd) {
-    // cell mode: does the row's cell table + weight table + ONE compact strip set fit this wave's LDS?
+    // Cell mode: the wave builds per window row a table of the cells it can touch (and, where it fits, of the guide weights) in
+    // LDS, next to ONE compact strip set, and the taps read those.
+    //   full  : every disparity of the level (d = 1 .. D) and the weight table -- the coarse levels, where that fits;
+    //   range : the levels above them, when every tap of every lane interpolates (the four window corners of each lane lie in
+    //           [1 + 2^-20, D - 2^-20]: the disparity is linear over the window up to two roundings of < 2^-43 each) and the wave's
+    //           integer disparities span few values [f_lo, f_hi]: a table of just those ND = f_hi - f_lo + 1 disparities, strips
+    //           of just the columns they need, the weight table when it still fits and per-tap weights when not.
+    // Same grd_cell(), same terms, same order: identical results whichever path a level takes.
     const int ncent = cmax - cmin + 1, NQ = o_len;
-    const int off_g = s_len * 16, off_p = off_g + (NQ * 8 + 15) / 16 * 16, off_c = off_p + (NQ * 4 + 15) / 16 * 16;  // 16-byte DMA pieces
-    const int off_w = off_c + NQ * D * 8, off_i = off_w + ncent * A.n * 8, cell_bytes = off_i + ncent * 4;
-    if (CSPM_CELL_MODE && staged && D >= 2 && cell_bytes + 64 <= wave_lds_bytes(ctx.cap, ctx.ocap)) {
+    const int lds_room = wave_lds_bytes(ctx.cap, ctx.ocap) - 64;
+    const int own_bytes = (NQ * 8 + 15) / 16 * 16 + (NQ * 4 + 15) / 16 * 16, wtab_bytes = ncent * A.n * 8 + ncent * 4;
+    int d_base = 1, ND = D;
+    bool cells_on = false, wtab = true, allv_level = false;
+    if (CSPM_CELL_MODE && staged && D >= 2) {
+      if ((NQ + D) * 16 + own_bytes + NQ * D * 8 + wtab_bytes <= lds_room) {
+        cells_on = true;
+#ifdef CSPM_ROW_STATS
+        if (lane == 0) atomicAdd(&g_rangestat[(ctx.stat_slot * 8 + s) * 8 + 7], 1ull);
+#endif
+      } else if (CSPM_RANGE_MODE && D < 512 && dy_lo <= dy_hi) {
+        const int jl = (A.n - 1) % kRowMod;
+        const double rt0 = b * (double)(cy - A.half + dy_lo) + c, rt1 = b * (double)(cy - A.half + dy_hi) + c;  // q_disp_y of the first / last row
+        const double q00 = tap_disp(a, 0.0, group_disp(a, qx0_d, rt0)), q01 = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rt0));
+        const double q10 = tap_disp(a, 0.0, group_disp(a, qx0_d, rt1)), q11 = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rt1));
+        const double qmin = __builtin_fmin(__builtin_fmin(q00, q01), __builtin_fmin(q10, q11));
+        const double qmax = __builtin_fmax(__builtin_fmax(q00, q01), __builtin_fmax(q10, q11));
+        const bool safe = (qmin >= 1.0 + 0x1p-20) & (qmax <= (double)D - 0x1p-20);  // false for NaN
+        int f_lo = safe ? (int)(qmin - 0x1p-20) : 1, f_hi = safe ? (int)(qmax + 0x1p-20) + 1 : 1;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
+          f_hi = max(f_hi, __shfl_xor(f_hi, off, kWave));
+        }
+        f_lo = __builtin_amdgcn_readfirstlane(f_lo);
+        f_hi = __builtin_amdgcn_readfirstlane(f_hi);
+        const int nd = f_hi - f_lo + 1;
+        const int base_bytes = (NQ + nd) * 16 + own_bytes + NQ * nd * 8;
+        if (__builtin_amdgcn_ballot_w64(!safe) == 0ull && (NQ + nd) <= kStripRegs * kWave) {
+          if (base_bytes + wtab_bytes <= lds_room) { cells_on = true; }
+          else if (!edge && base_bytes + (NQ * 4 + 15) / 16 * 16 <= lds_room) { cells_on = true; wtab = false; }  // + a second colour run, see below
+          if (cells_on) { d_base = f_lo; ND = nd; allv_level = true; }
+        }
+#ifdef CSPM_ROW_STATS
+        if (lane == 0) {
+          unsigned long long *g = &g_rangestat[(ctx.stat_slot * 8 + s) * 8];
+          atomicAdd(&g[0], 1ull);
+          if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) atomicAdd(&g[1], 1ull);
+          else if (cells_on) { atomicAdd(&g[wtab ? 2 : 3], 1ull); atomicAdd(&g[5], (unsigned long long)nd); }
+          else { atomicAdd(&g[4], 1ull); atomicAdd(&g[6], (unsigned long long)nd); }
+        }
+#endif
+      }
+    }
+    if (cells_on) {
+      // strip window of the table's disparities (padded columns): slot(q, d) = q + (d_base + ND - 1) - d for the left view,
+      // q + d - (d_base - 1) for the right view; NQ + ND slots
+      const int c_lo = VIEW == 0 ? L.pad + cmin - A.half - (d_base + ND - 1) : L.pad + cmin - A.half + (d_base - 1);
+      const int c_len = NQ + ND;
+      // LDS of the wave: slots | own gradients | own colours [| own colours of the other row parity] | cells | weights | centre colours.
+      // Per-tap weights (!wtab) read the own colours of the CURRENT row while the next row's strips arrive: that run is double-buffered.
+      const int p_bytes = (NQ * 4 + 15) / 16 * 16;
+      const int off_g = c_len * 16, off_p = off_g + (NQ * 8 + 15) / 16 * 16, off_c = off_p + (wtab ? 1 : 2) * p_bytes;  // 16-byte DMA pieces
+      const int off_w = off_c + NQ * ND * 8, off_i = off_w + ncent * A.n * 8;
       const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
       const size_t Wp = (size_t)L.Wp;
-      const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + s_lo) * 16);
+      const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + c_lo) * 16);
       const char *gg = uniform_ptr(reinterpret_cast<const char *>(L.grd[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 8);
       const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
       const int g_p16 = (NQ * 8 + 15) / 16, p_p16 = (NQ * 4 + 15) / 16;  // 16-byte pieces of the own view's gradient / colour runs
-      auto issue = [&]() {  // one compact strip set at lds0: slots | gradients | colours
+      auto issue = [&](int par) {  // one compact strip set at lds0: slots | gradients | colours (of row parity `par`)
 #pragma unroll
         for (int k = 0; k < kStripRegs; ++k)
-          if (k * kWave < s_len) {
-            if (lane + k * kWave < s_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, lds0 + (unsigned)k * 1024u);
+          if (k * kWave < c_len) {
+            if (lane + k * kWave < c_len) dma_b128(g16, (unsigned)(lane + k * kWave) * 16u, lds0 + (unsigned)k * 1024u);
           }
         if (lane < g_p16) dma_b128(gg, (unsigned)lane * 16u, lds0 + (unsigned)off_g);  // <= 64 pieces: the run has <= 128 columns
-        if (lane < p_p16) dma_b128(gp, (unsigned)lane * 16u, lds0 + (unsigned)off_p);
+        if (lane < p_p16) dma_b128(gp, (unsigned)lane * 16u, lds0 + (unsigned)(off_p + par * p_bytes));
         g16 += Wp * 16; gg += Wp * 8; gp += Wp * 4;
       };
       dma_wait();  // the previous level's LDS reads have returned
-      issue();
+      issue(0);
+      int par = 0;
       // the centres' colours (window centre row cy, fixed for the level): lanes with the same centre write the same word
       const int ipc_a = strip_a + off_i;
-      *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)(ipc_a + (cx - cmin) * 4) = Ip;
+      if (wtab) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)(ipc_a + (cx - cmin) * 4) = Ip;
       CellRow C;
       C.stride = NQ * 8;
-      C.adr_c = strip_a + off_c + (cx - cmin) * 8 - C.stride;  // cells[d][q] holds disparity d + 1: f indexes row f - 1
+      C.adr_c = strip_a + off_c + (cx - cmin) * 8 - d_base * C.stride;  // table row k holds disparity d_base + k: f indexes row f - d_base
       C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
       C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
       asm volatile("" : "+v"(C.adr_w2));
       asm volatile("" : "+v"(C.adr_w3));
       asm volatile("" : "+v"(C.adr_w4));
+      C.Ip = Ip;
       const int gcol0 = cmin - A.half;  // image column of table column q = 0
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
         dma_wait();  // the strips of row dy have landed; the taps of row dy-1 have read their tables
-        // ---- cells[d][q], d = 0 .. D-1 for disparities 1 .. D: lane = table column q (its own element is read once), disparities in
-        // batches of four (an entry is a chain of three dependent LDS round trips; the batch overlaps them).  The other view's slot
-        // moves one slot per disparity and the table one row: every address in the batch is an immediate off two running bases.
+        // ---- cells[k][q], k = 0 .. ND-1 for disparities d_base .. d_base+ND-1: lane = table column q (its own element is read once),
+        // disparities in batches of four (an entry is a chain of three dependent LDS round trips; the batch overlaps them).  The other
+        // view's slot moves one slot per disparity and the table one row: every address in the batch is an immediate off two running bases.
         for (int q0 = 0; q0 < NQ; q0 += kWave) {  // one trip unless the row has more than 64 columns
           const int q = q0 + lane;
           const bool qon = q < NQ;
           const int qs = qon ? q : 0;
           const uint2 gq2 = lds_ld<uint2>(strip_a + off_g + qs * 8);
-          const uint32_t pq = lds_ld<uint32_t>(strip_a + off_p + qs * 4);
+          const uint32_t pq = lds_ld<uint32_t>(strip_a + off_p + par * p_bytes + qs * 4);
           const double gq = __hiloint2double((int)gq2.y, (int)gq2.x);
-          int adr_s = strip_a + (VIEW == 0 ? qs - 1 + D : qs + 1) * 16;  // slot of disparity 1
-          int adr_t = strip_a + off_c + qs * 8;                            // cells[0][q]
+          int adr_s = strip_a + (VIEW == 0 ? qs + ND - 1 : qs + 1) * 16;  // slot of disparity d_base
+          int adr_t = strip_a + off_c + qs * 8;                             // cells[0][q]
           constexpr int U = 4;
-          for (int d0 = 0; d0 < D; d0 += U) {
+          for (int d0 = 0; d0 < ND; d0 += U) {
             uint4 o[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) o[u] = lds_ld<uint4>(adr_s + (VIEW == 0 ? -16 : 16) * u);  // d0 + u < D + U: the strip set has the room
+            for (int u = 0; u < U; ++u) o[u] = lds_ld<uint4>(adr_s + (VIEW == 0 ? -16 : 16) * u);  // beyond ND: inside the wave's LDS, the value is not stored
             double cell[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) cell[u] = grd_cell(lut.a, pq, gq, o[u].z, __hiloint2double((int)o[u].y, (int)o[u].x));
             int at = adr_t;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              if (qon && d0 + u < D) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)at = cell[u];
+              if (qon && d0 + u < ND) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)at = cell[u];
               at += C.stride;
             }
             adr_s += (VIEW == 0 ? -16 : 16) * U;
@@ -629,46 +710,58 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           }
         }
         // ---- wgts[c][j]: lane = window column j, one centre per trip (its colour is one broadcast read)
-        for (int j0 = 0; j0 < A.n; j0 += kWave) {
-          const int j = j0 + lane;
-          const bool jon = j < A.n;
-          const int js = jon ? j : 0;
-          int adr_p = strip_a + off_p + js * 4, adr_o = strip_a + off_w + js * 8;
-          int col = gcol0 + js;
-          constexpr int U = 4;
-          for (int c0 = 0; c0 < ncent; c0 += U) {
-            uint32_t ic[U], pq[U];
+        if (wtab) {
+          for (int j0 = 0; j0 < A.n; j0 += kWave) {
+            const int j = j0 + lane;
+            const bool jon = j < A.n;
+            const int js = jon ? j : 0;
+            int adr_p = strip_a + off_p + js * 4, adr_o = strip_a + off_w + js * 8;
+            int col = gcol0 + js;
+            constexpr int U = 4;
+            for (int c0 = 0; c0 < ncent; c0 += U) {
+              uint32_t ic[U], pq[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              ic[u] = lds_ld<uint32_t>(ipc_a + (c0 + u) * 4);  // c0 + u < ncent + U: inside the wave's LDS, the value is not used beyond ncent
-              pq[u] = lds_ld<uint32_t>(adr_p + u * 4);
-            }
-            double w[U];
+              for (int u = 0; u < U; ++u) {
+                ic[u] = lds_ld<uint32_t>(ipc_a + (c0 + u) * 4);  // c0 + u < ncent + U: inside the wave's LDS, the value is not used beyond ncent
+                pq[u] = lds_ld<uint32_t>(adr_p + u * 4);
+              }
+              double w[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              int sad = (int)__builtin_amdgcn_sad_u8(ic[u], pq[u], 0u);
-              sad = ((unsigned)(col + u) < (unsigned)A.W) ? sad : kLutZero;  // outside the image: weight 0, the tap adds +0.0
-              w[u] = lut.w[sad];
-            }
-            int ao = adr_o;
+              for (int u = 0; u < U; ++u) {
+                int sad = (int)__builtin_amdgcn_sad_u8(ic[u], pq[u], 0u);
+                sad = ((unsigned)(col + u) < (unsigned)A.W) ? sad : kLutZero;  // outside the image: weight 0, the tap adds +0.0
+                w[u] = lut.w[sad];
+              }
+              int ao = adr_o;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              if (jon && c0 + u < ncent) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)ao = w[u];
-              ao += A.n * 8;
+              for (int u = 0; u < U; ++u) {
+                if (jon && c0 + u < ncent) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)ao = w[u];
+                ao += A.n * 8;
+              }
+              adr_p += U * 4; adr_o = ao; col += U;
             }
-            adr_p += U * 4; adr_o = ao; col += U;
           }
         }
-        dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go
-        if (dy < dy_hi) issue();
         const double rowterm = b * (double)qy + c;  // q_disp_y, :155
-        const int jl = (A.n - 1) % kRowMod;
-        const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
-        const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
-        const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
-        const bool safe = (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
-        const double Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? cell_row_taps<true>(A, C, a, rowterm, qx0_d)
-                                                                       : cell_row_taps<false>(A, C, a, rowterm, qx0_d);
+        double Rsum;
+        dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go
+        C.adr_p = strip_a + off_p + par * p_bytes + (cx - cmin) * 4;  // this row's own colours (per-tap weights)
+        if (!wtab) par ^= 1;
+        if (dy < dy_hi) issue(par);
+        if (wtab) {
+          bool allv = allv_level;
+          if (!allv_level) {  // full tables: decide per row whether every tap interpolates (see the general path below)
+            const int jl = (A.n - 1) % kRowMod;
+            const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+            const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+            const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+            const bool safe = (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+            allv = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
+          }
+          Rsum = allv ? cell_row_taps<true, true>(A, lut, C, a, rowterm, qx0_d) : cell_row_taps<false, true>(A, lut, C, a, rowterm, qx0_d);
+        } else {
+          Rsum = cell_row_taps<true, false>(A, lut, C, a, rowterm, qx0_d);
+        }
         tree.push(dy, Rsum);
         if (all_rejected(Rsum)) { dma_wait(); return __builtin_inf(); }
       }
