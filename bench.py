@@ -10,7 +10,7 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank pr
 (weak scaling, no data-path collective), value = all pairs' pixels / max-over-ranks time.
 `python bench.py --gpus N` without a launcher spawns the N ranks itself.
 
-Pairs are independent units: by default three of them are in flight per GPU (three contexts, three HIP streams), so the
+Pairs are independent units: by default two of them are in flight per GPU (two contexts, two HIP streams), so the
 CUs the raster sweep of one pair leaves idle (short anti-diagonals) evaluate the other pair's planes; all K pairs
 complete inside the timed region.  --in-flight 1 gives the one-pair-at-a-time number.
 
@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C4 | C5 (crossscalepatchmatch_amd/synth.py); C4 = the batch of C3-shaped pairs "
                                                    "held by rank 0 and dispatched through crossscalepatchmatch_amd.batch.run_batch")
     ap.add_argument("--same-pair", action="store_true", help="time one pair K times instead of K distinct pairs (seeds base + k)")
-    ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams)")
+    ap.add_argument("--in-flight", type=int, default=2, help="stereo pairs in flight per GPU (contexts / HIP streams)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)
     ap.add_argument("--no-early-exit", action="store_true")

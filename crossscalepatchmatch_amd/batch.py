@@ -44,7 +44,7 @@ class HipPairFn:
     lets a collective overwrite a receive buffer, and finalize() before it reads the maps."""
     writes_out = True
 
-    def __init__(self, device_index, in_flight=3):
+    def __init__(self, device_index, in_flight=2):
         import torch
         from .capi import StereoContext
         self.device = torch.device("cuda", device_index)
@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--schedule", type=int, default=0)
     ap.add_argument("--use_pp", type=int, default=0)
     ap.add_argument("--cc", default="GRD", choices=sorted(CC_CODES))
-    ap.add_argument("--in-flight", type=int, default=3)
+    ap.add_argument("--in-flight", type=int, default=2)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

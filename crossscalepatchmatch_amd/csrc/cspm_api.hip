@@ -88,6 +88,9 @@ struct cspm_ctx {
   long long sweep_pairs_limit = 4LL << 30;  // bytes of paired-cell volumes a context may hold (env CSPM_SWEEP_PAIRS_MAX_MB)
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   unsigned long long *d_maxkeys = nullptr;
+  int row_claim = -1;  // row kernels: -1 = claimed column bands for launches of several rounds (default), 0 / 1 = never / always (env CSPM_ROW_CLAIM, tests)
+  unsigned int *d_rowq = nullptr;  // row kernels: a ring of claim-counter sets (8 counters each), one set per launch (cspm_rows.h row_item)
+  int rowq_next = 0;
   // plane field
   bool field_alloc = false;
   bool field_consistent = false;  // every min_cost was computed from the stored plane by this cost object (not by cspm_set_planes)
@@ -202,13 +205,31 @@ int drain_timing(cspm_ctx *c) {
 }
 
 // row engine: one wave per 64-pixel run of an image row, kRowWaves waves per workgroup, grid a multiple of 8 (XCD bands)
-inline unsigned row_grid(int W, int H, int views) {
-  const long long per_xcd = (row_items_per_xcd(W, H, views) + kRowWaves - 1) / kRowWaves;  // workgroups per XCD (cspm_rows.h: row_item)
+// a row-kernel launch: claimed column bands when it runs for several rounds of resident waves, interleaved row blocks otherwise
+// (cspm_rows.h row_item); workgroups of kRowWaves waves, grid a multiple of 8
+inline bool row_claimed(const cspm_ctx *c, int views) {
+  const long long items = row_items(c->W, c->H, views);
+  if (items >= (1LL << 31)) return false;
+  if (c->row_claim >= 0) return c->row_claim != 0;
+  return items >= 2LL * c->ncu * 12;  // two rounds of the 12 waves a CU holds (a KITTI-size pair: every row kernel; a 450 x 375 pair: none)
+}
+inline unsigned row_grid(const cspm_ctx *c, int views) {
+  const bool claimed = row_claimed(c, views);
+  long long per_xcd = (row_items_per_xcd(c->W, c->H, views, claimed) + kRowWaves - 1) / kRowWaves;
+  if (claimed) per_xcd += per_xcd / 4 + 1;  // the surplus workgroups of the XCDs that finish first take over the others' bands
   return (unsigned)(per_xcd * 8);
 }
 inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
 inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }
 inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * wave_lds_bytes(row_cap(c), row_ocap(c)); }
+
+// the claim counters of the next row-kernel launch, zeroed on the stream right before it; none for a launch of interleaved row blocks
+constexpr int kRowQueueSets = 1;
+inline RowQueue next_row_queue(cspm_ctx *c, int views) {
+  if (!row_claimed(c, views)) return RowQueue{nullptr};
+  (void)hipMemsetAsync(c->d_rowq, 0, 8 * sizeof(unsigned int), c->stream);
+  return RowQueue{c->d_rowq};
+}
 
 inline unsigned eval_grid(long long items) {
   long long nb = (items + (kEvalBlock / kWave) - 1) / (kEvalBlock / kWave);
@@ -239,6 +260,8 @@ void free_field(cspm_ctx *c) {
   }
   if (c->d_todo) (void)hipFree(c->d_todo);
   c->d_todo = nullptr;
+  if (c->d_rowq) (void)hipFree(c->d_rowq);
+  c->d_rowq = nullptr;
   if (c->fpm.xy) (void)hipFree(c->fpm.xy);
   if (c->fpm.view) (void)hipFree(c->fpm.view);
   if (c->fpm.plane) (void)hipFree(c->fpm.plane);
@@ -529,6 +552,7 @@ int ensure_field(cspm_ctx *c) {
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
   }
   if ((rc = dalloc(c, &c->d_todo, 2 * n + 2, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->d_rowq, 8 * kRowQueueSets, nullptr))) return rc;
   // persistent sweep state: control words, per-pixel granules (tag zero = never written), diagonal start table
   if ((rc = dalloc(c, &c->d_sweep_ctrl, 2 + kSweepMaxBands, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, (2 + kSweepMaxBands) * sizeof(unsigned int), c->stream));
@@ -671,7 +695,8 @@ int do_init(cspm_ctx *c, const cspm_pm_params *p) {
   Pm pm = make_pm(c, p);
   {
     Timed t(c, CSPM_K_INIT, items);
-    LAUNCH_CS(k_init, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, row_cap(c), row_ocap(c));
+    const RowQueue rq = next_row_queue(c, 2);
+    LAUNCH_CS(k_init, dim3(row_grid(c, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, rq, row_cap(c), row_ocap(c));
   }
   HIPCHK(c, hipGetLastError());
   c->field_consistent = true;
@@ -753,7 +778,8 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   for (int v = 0; v < 2; ++v) {
     {
       Timed t(c, CSPM_K_VIEW, items);
-      LAUNCH_CS(k_view_eval, dim3(row_grid(c->W, c->H, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, v, c->vc, row_cap(c), row_ocap(c));
+      const RowQueue rq = next_row_queue(c, 1);
+      LAUNCH_CS(k_view_eval, dim3(row_grid(c, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, rq, v, c->vc, row_cap(c), row_ocap(c));
     }
     {
       Timed t(c, CSPM_K_MISC, 0);
@@ -776,7 +802,8 @@ int do_refine(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   for (int first = 0; first < steps; first += c->refine_chunk) {
     const int cnt = std::min(c->refine_chunk, steps - first);
     Timed t(c, CSPM_K_REFINE, items * cnt);
-    LAUNCH_CS(k_refine, dim3(row_grid(c->W, c->H, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, iter, first, cnt, z, nn, row_cap(c), row_ocap(c));
+    const RowQueue rq = next_row_queue(c, 2);
+    LAUNCH_CS(k_refine, dim3(row_grid(c, 2)), dim3(kRowBlock), row_shmem(c), c->cost, pm, rq, iter, first, cnt, z, nn, row_cap(c), row_ocap(c));
     for (int k = 0; k < cnt; ++k) { z /= 2.0; nn /= 2.0; }
   }
   HIPCHK(c, hipGetLastError());
@@ -870,6 +897,7 @@ int cspm_create(cspm_ctx **out, int device) {
   c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("CSPM_REFINE_CHUNK")) c->refine_chunk = std::max(1, atoi(e));
   if (const char *e = getenv("CSPM_SWEEP_WG")) c->sweep_wg_per_cu = std::max(1, atoi(e));
+  if (const char *e = getenv("CSPM_ROW_CLAIM")) c->row_claim = atoi(e) < 0 ? -1 : (atoi(e) ? 1 : 0);
   if (const char *e = getenv("CSPM_SWEEP_BANDS")) c->sweep_bands = std::max(1, std::min(kSweepMaxBands, atoi(e)));
   if (const char *e = getenv("CSPM_SWEEP_PAIRS")) c->opt_sweep_pairs = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;

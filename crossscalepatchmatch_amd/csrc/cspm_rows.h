@@ -981,42 +981,70 @@ __device__ __forceinline__ double eval_rows(const Cost &cd, const Luts &lut, con
                    : eval_rows_view<CS, SRC, 1>(cd, lut, ctx, x, gen, thresh, use_thresh);
 }
 
-// pixel run of this wave: item = (view, y, 64-pixel segment).  Workgroups are dealt round-robin to the 8 XCDs (each with its
-// own L2); the image rows (both views stacked) are cut into blocks of kRowBand rows and XCD k works through blocks k, k+8,
-// k+16, ... in order: what runs on an XCD at any time is ~1.5 blocks of neighbouring rows (window rows are shared in its L2),
-// and every XCD gets the same mix of image top, middle and bottom -- border rows have clipped windows and are cheaper, so
-// contiguous eighths of the image left half of the XCDs idle at the end (measured, CSPM_ROW_BAND).  Returns false past the end.
+// Pixel run of a wave: item = (view, y, 64-pixel segment).  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB
+// L2; blockIdx % 8 -- an assumption that only locality and balance rest on).  Two ways of handing out the items, chosen per launch:
+//
+//  * CLAIMED COLUMN BANDS (launches of two or more rounds of resident waves: the row kernels of a KITTI-size or larger pair).  The items in (segment, view, row) order are cut into eight equal runs; a wave takes the next item of the
+//    run of its XCD from that run's counter and, when the run is exhausted, of the next run that still has items.  An XCD thus works
+//    through ~segs/8 adjacent 64-column segments of every row of both views: its L2 holds a (3 x 64 + window + disparity range)-
+//    column band of the level images instead of seeing all of them (k_refine on C3: L2 hit rate 64 % -> 95 %, fabric traffic / 8,
+//    L1 return path -22 %), consecutive claims are vertically adjacent rows, and the XCDs whose bands are cheaper (no image border)
+//    finish the others' bands -- the launch has 25 % more workgroups than items for that; the surplus finds every run empty and leaves.
+//  * INTERLEAVED ROW BLOCKS (launches that fit the GPU in less than two rounds, where little can be re-balanced while it runs): the
+//    image rows (both views stacked) are cut into blocks of kRowBand rows, XCD k works through blocks k, k+8, k+16, ... and a
+//    workgroup takes x-adjacent segments of one row: every XCD and every CU gets the same mix of image top, middle, bottom and
+//    border columns (border rows have clipped windows and are cheaper, border columns carry the column mask and are dearer;
+//    contiguous eighths of the image left half of the XCDs idle at the end -- measured, CSPM_ROW_BAND).
 #ifndef CSPM_ROW_BAND
 #define CSPM_ROW_BAND 4
-#endif
-#ifndef CSPM_ROW_VERT
-#define CSPM_ROW_VERT 0
 #endif
 constexpr int kRowBand = CSPM_ROW_BAND;
 struct RowItem {
   int v, y, x0;
 };
-__host__ __device__ inline long long row_items_per_xcd(int W, int H, int views) {
+struct RowQueue {
+  unsigned int *next;  // claimed column bands: [8] items claimed from run k so far, zeroed before the launch; null: interleaved row blocks
+};
+__host__ __device__ inline long long row_items(int W, int H, int views) { return (long long)((W + kWave - 1) / kWave) * views * H; }
+__host__ __device__ inline long long row_items_per_xcd(int W, int H, int views, bool claimed) {
   const int segs = (W + kWave - 1) / kWave;
+  if (claimed) return (row_items(W, H, views) + 7) / 8;
   const int nblk = (views * H + kRowBand - 1) / kRowBand;
   return (long long)((nblk + 7) / 8) * kRowBand * segs;
 }
-__device__ __forceinline__ bool row_item(int W, int H, int views, RowItem &it) {
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+__device__ __forceinline__ bool row_item(int W, int H, int views, const RowQueue &rq, RowItem &it) {
   const int segs = (W + kWave - 1) / kWave;
   const int xcd = (int)(blockIdx.x % 8u);
+  if (rq.next) {
+    const long long total = row_items(W, H, views), per = row_items_per_xcd(W, H, views, true);
+    long long g = -1;
+    if ((threadIdx.x & 63) == 0) {
+      for (int t = 0; t < 8 && g < 0; ++t) {
+        const int q = (xcd + t) & 7;
+        const long long lo = (long long)q * per;
+        const long long cnt = lo + per <= total ? per : total - lo;
+        if (cnt <= 0) continue;
+        if ((long long)__hip_atomic_load(&rq.next[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
+        const long long i = (long long)__hip_atomic_fetch_add(&rq.next[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < cnt) g = lo + i;
+      }
+    }
+    const int gi = __builtin_amdgcn_readfirstlane((int)g);  // < 2^31 items
+    if (gi < 0) return false;
+    const int seg = gi / (views * H);
+    const int rem = gi - seg * (views * H);
+    it.v = rem / H;
+    it.y = rem - it.v * H;
+    it.x0 = seg * kWave;
+    return true;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long e = (long long)(blockIdx.x / 8u) * kRowWaves + wave;  // index among this XCD's waves
-  if (e >= row_items_per_xcd(W, H, views)) return false;
+  if (e >= row_items_per_xcd(W, H, views, false)) return false;
   const int per_blk = kRowBand * segs;
   const int blk_local = (int)(e / per_blk);
   const int rem = (int)(e - (long long)blk_local * per_blk);
-#if CSPM_ROW_VERT
-  // the waves of a workgroup (consecutive e) take the SAME 64-column segment of vertically adjacent rows: their 35-row windows
-  // overlap 31/35, so the strip rows one wave fetches are in the CU's L1 / the XCD's L2 when the next wave asks for them
-  const int seg = rem / kRowBand, row_in_blk = rem - seg * kRowBand;
-#else
   const int row_in_blk = rem / segs, seg = rem - row_in_blk * segs;
-#endif
   const int row = (blk_local * 8 + xcd) * kRowBand + row_in_blk;  // row of the stacked views
   if (row >= views * H) return false;
   it.v = row / H;
@@ -1056,12 +1084,12 @@ __device__ __forceinline__ RowPlane init_plane(const Pm &pm, int v, int x, int y
 }
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_INIT_MINW) void k_init(Cost cd, Pm pm, int cap, int ocap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_INIT_MINW) void k_init(Cost cd, Pm pm, RowQueue rq, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
-  if (!row_item(pm.W, pm.H, 2, it)) return;
+  if (!row_item(pm.W, pm.H, 2, rq, it)) return;
   const int lane = threadIdx.x & 63;
   RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
@@ -1100,12 +1128,12 @@ __device__ __forceinline__ RowPlane refine_plane(const Pm &pm, int v, int x, int
 }
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm pm, int iter, int first_step, int nsteps, double z_iter, double n_iter, int cap, int ocap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm pm, RowQueue rq, int iter, int first_step, int nsteps, double z_iter, double n_iter, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
-  if (!row_item(pm.W, pm.H, 2, it)) return;
+  if (!row_item(pm.W, pm.H, 2, rq, it)) return;
   const int lane = threadIdx.x & 63;
   RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
   const bool live = it.x0 + lane < pm.W;
@@ -1168,12 +1196,12 @@ __device__ __forceinline__ ViewProposal view_proposal(const Pm &pm, int v, int x
 }
 
 template <bool CS, int SRC>
-__global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd, Pm pm, int v, ViewCand vc, int cap, int ocap) {
+__global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd, Pm pm, RowQueue rq, int v, ViewCand vc, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LutMem &s_lut = *reinterpret_cast<LutMem *>(smem);
   const Luts lut = load_luts(cd, s_lut);
   RowItem it;
-  if (!row_item(pm.W, pm.H, 1, it)) return;
+  if (!row_item(pm.W, pm.H, 1, rq, it)) return;
   const int lane = threadIdx.x & 63;
   RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
 #ifdef CSPM_ROW_STATS

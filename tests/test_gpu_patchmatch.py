@@ -487,6 +487,38 @@ def test_sweep_row_bands_and_paired_cells(gpu_ctx):
             ctx.close()
 
 
+@pytest.mark.parametrize("w,h,D", [(1, 1, 2), (9, 2, 4), (37, 3, 6), (77, 41, 21), (200, 70, 24)])
+def test_row_kernels_claimed_column_bands(gpu_ctx, w, h, D):
+    """The row kernels hand their items out in two ways (cspm_rows.h row_item): interleaved row blocks, and column bands claimed from
+    eight counters with 25 % surplus workgroups -- by default only launches of several rounds of resident waves (k_init / k_refine of
+    a KITTI-size pair) take the latter.  CSPM_ROW_CLAIM=1 forces it on small and ragged images: every pixel must still be evaluated
+    exactly once -- planes, costs and post-processed maps equal the default context's."""
+    import os
+    import crossscalepatchmatch_amd as cs
+    rng = np.random.default_rng(w * 1000 + h)
+    l = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    r = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    os.environ["CSPM_ROW_CLAIM"] = "1"
+    try:
+        ctx = cs.StereoContext(0)
+    finally:
+        del os.environ["CSPM_ROW_CLAIM"]
+    try:
+        for sn, lam in ((0, 0.0), (5, 0.3)):
+            out = []
+            for c in (gpu_ctx, ctx):
+                c.set_images(l, r)
+                c.build_cost_grd(D, 35, sn, lam)
+                c.patchmatch(2, seed=3, schedule=0)
+                out.append([c.get_planes(v) for v in (0, 1)] + list(c.postprocess(2)))
+            for v in (0, 1):
+                np.testing.assert_array_equal(out[0][v][0], out[1][v][0])
+                np.testing.assert_array_equal(out[0][v][1], out[1][v][1])
+                np.testing.assert_array_equal(out[0][2 + v], out[1][2 + v])
+    finally:
+        ctx.close()
+
+
 def test_new_cost_object_withdraws_the_stored_costs(gpu_ctx, small_pair):
     """The sweep skips a neighbour plane that is bitwise the pixel's own plane (its cost would be the stored min_cost) -- only
     while every stored cost was computed by the CURRENT cost object.  Rebuilding the cost (census -> GRD here) on the same
