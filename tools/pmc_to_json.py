@@ -40,6 +40,7 @@ res = {
     "ta_busy_frac": per["TA_TA_BUSY_sum"] / 256 / gui, "td_busy_frac": per["TD_TD_BUSY_sum"] / 256 / gui,
     "waves_per_launch": per["SQ_WAVES"], "mean_waves_per_simd": per["SQ_WAVE_CYCLES"] * 4 / 1024 / gui,
     "fetch_size_kb": per.get("FETCH_SIZE"), "write_size_kb": per.get("WRITE_SIZE"),
+    "l2_hit_rate": (per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])) if per.get("TCC_HIT_sum") is not None and per.get("TCC_MISS_sum") is not None else None,
     # HBM bytes: 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md for wide reads; an upper bound otherwise) + WRITE_SIZE
     "hbm_bytes_per_launch": (2 * per.get("FETCH_SIZE", 0) + per.get("WRITE_SIZE", 0)) * 1024,
     "raw_per_launch": per,

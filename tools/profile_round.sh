@@ -28,6 +28,15 @@ for C in C1 C2 C4 C5; do
   python bench.py --config $C --no-cpu-baseline --steps $S --warmup 2 > $O/bench_$(echo $C | tr A-Z a-z).json 2> /dev/null
 done
 ./tools/ubench/valu_issue > $O/valu_issue.txt 2>&1
+# 6. the RCCL code path on this one GPU: a process group of world size 1, C4 dispatched by run_batch's broadcast / scatter / gather
+cd /tmp
+CSPM_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rccl -o t -- python $R/bench.py --config C4 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_c4_rccl.json 2> /dev/null
+# 7. how the pairs in flight overlap
+rocprofv3 --kernel-trace --output-format csv -d $O/overlap -o t -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+cd $R
+python tools/overlap_timeline.py $O/overlap/t_kernel_trace.csv > $O/overlap_inflight.txt
+python tools/concurrent_phases.py C3 > $O/concurrent_phases.txt 2>&1
+grep -i "nccl\|rccl" $O/rccl/t_kernel_stats.csv | cut -c1-160
 python tools/bench_brief.py default < $O/bench_default.json
 python tools/bench_brief.py inflight1 < $O/bench_inflight1.json
 head -4 $O/trace/t_kernel_stats.csv | cut -c1-150
