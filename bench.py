@@ -137,6 +137,9 @@ def main():
     # ONE JSON line on stdout, nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL prints a
     # five-line version banner there when a communicator is created).  Keep the real stdout for the result line and point fd 1 at
     # stderr for everything else, in this process and in whatever it loads.
+    # HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; two pair streams on one queue run one after the other
+    # (seen with streams from torch's pool).  The contexts own their streams and did not collide, but leave more queues than streams.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)

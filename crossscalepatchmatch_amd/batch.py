@@ -37,11 +37,13 @@ class HipPairFn:
     waits on the host per pair -- finalize() synchronises every context once, which is also where an error inside an
     asynchronous run (a sweep that timed out with more than one pair enqueued) is raised.
 
-    Stream ordering: before a pair is enqueued its stream waits (device-side) for torch's current stream -- the one the
-    NCCL/RCCL scatter was ordered into by Work.wait() -- so k_pack_bgr never reads a half-received input block.  The pair
-    writes its maps straight into the caller's output views (`out=`); torch's current stream is NOT made to wait per pair
-    (that would chain the pairs of different contexts one after the other): run_batch calls order_after_pairs() before it
-    lets a collective overwrite a receive buffer, and finalize() before it reads the maps."""
+    Stream ordering: before a pair is enqueued its stream waits (device-side) for the event `after` -- recorded by run_batch on
+    torch's current stream right after Work.wait() ordered the NCCL/RCCL scatter of the pair's block into it -- or, without one,
+    for torch's current stream as it is now; so k_pack_bgr never reads a half-received input block.  The pair writes its maps
+    straight into the caller's output views (`out=`); torch's current stream is NOT made to wait per pair (that would chain the
+    pairs of different contexts one after the other): run_batch calls order_after_pairs() before it lets a collective overwrite
+    a receive buffer, and finalize() before it reads the maps.  The tensors a pair reads and writes are kept referenced until
+    finalize() (they are used on streams torch's allocator does not own)."""
     writes_out = True
 
     def __init__(self, device_index, in_flight=2):
@@ -49,20 +51,25 @@ class HipPairFn:
         from .capi import StereoContext
         self.device = torch.device("cuda", device_index)
         self.ctxs = [StereoContext(device_index) for _ in range(max(1, int(in_flight)))]  # raises CspmError without libcspm_hip.so / a device
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.ctxs]
-        for c, st in zip(self.ctxs, self.streams):
-            c.set_stream(st.cuda_stream)
+        # every context runs on the non-blocking HIP stream it owns; torch sees it as an ExternalStream for the waits below.  (Streams
+        # from torch's pool may share a hardware queue -- with GPU_MAX_HW_QUEUES at its default, two of them did: the pairs of
+        # two contexts then ran strictly one after the other, 192 instead of 172 ms per KITTI-size pair.)
+        self.streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=self.device) for c in self.ctxs]
         self.calls = 0
         self.ctx = self.ctxs[0]
+        self._held = []  # tensors in use by pairs that have been enqueued but not yet synchronised
 
-    def __call__(self, l, r, p, out=None):
+    def __call__(self, l, r, p, out=None, after=None):
         import torch
         h, w = int(p["h"]), int(p["w"])
         assert l.is_cuda and l.device == self.device and l.is_contiguous() and r.is_contiguous()
         k = self.calls % len(self.ctxs)
         self.calls += 1
         ctx, stream = self.ctxs[k], self.streams[k]
-        stream.wait_stream(torch.cuda.current_stream(self.device))
+        if after is not None:
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(torch.cuda.current_stream(self.device))
         ctx.set_images_device(l.data_ptr(), r.data_ptr(), w, h, w * 3)
         cc = int(p.get("cc", 0))
         args = (int(p["max_dis"]), 35, int(p["scale_num"]), float(p["reg_lambda"]))
@@ -76,8 +83,7 @@ class HipPairFn:
         if out is None:
             out = [torch.empty((h, w), dtype=torch.uint8, device=l.device) for _ in range(2)]
         assert all(o.is_contiguous() and o.device == self.device and o.dtype == torch.uint8 for o in out)
-        for t in (out[0], out[1], l, r):
-            t.record_stream(stream)
+        self._held.append((out[0], out[1], l, r))
         if int(p["use_pp"]):
             ctx.postprocess_device(int(p["dis_scale"]), out[0].data_ptr(), out[1].data_ptr())
         else:
@@ -94,8 +100,11 @@ class HipPairFn:
 
     def finalize(self):
         """host-synchronise every context: raises if anything inside the asynchronous runs failed"""
-        for c in self.ctxs:
-            c.synchronize()
+        try:
+            for c in self.ctxs:
+                c.synchronize()
+        finally:
+            self._held.clear()
 
     def close(self):
         try:
@@ -140,12 +149,12 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4, fo
     first = partition(n, world, rank)[0]
     out = torch.zeros((cap, 2, h, w), dtype=torch.uint8, device=dev)
 
-    def compute(block, base, count):  # the hot path, pair by pair, no communication
+    def compute(block, base, count, after=None):  # the hot path, pair by pair, no communication
         for i in range(count):
             q = dict(p)
             q["seed"] = int(p["seed"]) + first + base + i  # per-pair seed = global pair index
             if getattr(pair_fn, "writes_out", False):  # the maps land in `out` directly, nothing is ordered into torch's stream
-                pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q, out=(out[base + i, 0], out[base + i, 1]))
+                pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q, out=(out[base + i, 0], out[base + i, 1]), after=after)
             else:
                 dl, dr = pair_fn(block[i, 0].contiguous(), block[i, 1].contiguous(), q)
                 out[base + i, 0], out[base + i, 1] = dl, dr
@@ -177,10 +186,16 @@ def run_batch(pairs, params, pair_fn, device="cpu", dist=None, chunk_pairs=4, fo
         work = issue(0) if rounds else None
         for j in range(rounds):
             work.wait()
+            # this round's pairs wait for exactly this: the scatter of their block.  (Waiting for the current stream itself would,
+            # from the second round on, also wait for everything order_after_pairs() puts into it: a barrier between rounds.)
+            ready = None
+            if dev.type == "cuda" and getattr(pair_fn, "writes_out", False):
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
             if j >= 1 and hasattr(pair_fn, "order_after_pairs"):
                 pair_fn.order_after_pairs()  # round j+1 lands in the buffer round j-1's pairs read
             nxt = issue(j + 1) if j + 1 < rounds else None
-            compute(recv[j % 2], j * chunk, max(0, min(chunk, sizes[rank] - j * chunk)))
+            compute(recv[j % 2], j * chunk, max(0, min(chunk, sizes[rank] - j * chunk)), after=ready)
             work = nxt
     else:
         compute(torch.as_tensor(pairs, dtype=torch.uint8).to(dev), 0, sizes[rank])

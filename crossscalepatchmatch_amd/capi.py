@@ -23,7 +23,7 @@ OPT_SWEEP_PAIRS_ACTIVE = 6   # read only
 
 # every symbol include/cspm.h declares
 SYMBOLS = [
-    "cspm_device_count", "cspm_create", "cspm_destroy", "cspm_last_error", "cspm_set_stream", "cspm_synchronize",
+    "cspm_device_count", "cspm_create", "cspm_destroy", "cspm_last_error", "cspm_set_stream", "cspm_get_stream", "cspm_synchronize",
     "cspm_set_images", "cspm_set_images_device", "cspm_build_cost_grd", "cspm_build_cost_cen", "cspm_build_cost_img", "cspm_cen_build_cv_host", "cspm_set_option", "cspm_get_option", "cspm_begin_cost", "cspm_upload_cost_slab",
     "cspm_finish_cost", "cspm_get_levels", "cspm_get_level_dims", "cspm_get_level_image", "cspm_get_cost_slab",
     "cspm_get_max_cost", "cspm_get_scale_weights", "cspm_grd_build_cv_host", "cspm_plane_cost_batch",
@@ -77,6 +77,7 @@ def load_library():
         "cspm_destroy": (None, [vp]),
         "cspm_last_error": (C.c_char_p, [vp]),
         "cspm_set_stream": (C.c_int, [vp, vp]),
+        "cspm_get_stream": (C.c_int, [vp, C.POINTER(vp)]),
         "cspm_synchronize": (C.c_int, [vp]),
         "cspm_set_images": (C.c_int, [vp, u8p, u8p, C.c_int, C.c_int, C.c_size_t]),
         "cspm_set_images_device": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_size_t]),
@@ -175,6 +176,12 @@ class StereoContext:
 
     def set_stream(self, stream_ptr):
         self._chk(self.L.cspm_set_stream(self.p, C.c_void_p(stream_ptr)))
+
+    def stream_ptr(self):
+        """the hipStream_t the context enqueues on, as an integer (torch.cuda.ExternalStream(ptr))"""
+        p = C.c_void_p()
+        self._chk(self.L.cspm_get_stream(self.p, C.byref(p)))
+        return p.value or 0
 
     def synchronize(self):
         self._chk(self.L.cspm_synchronize(self.p))

@@ -935,6 +935,12 @@ int cspm_set_stream(cspm_ctx *c, void *s) {
   return CSPM_OK;
 }
 
+int cspm_get_stream(cspm_ctx *c, void **out) {
+  if (!c || !out) return CSPM_ERR_ARG;
+  *out = (void *)c->stream;
+  return CSPM_OK;
+}
+
 int cspm_synchronize(cspm_ctx *c) {
   if (!c) return CSPM_ERR_ARG;
   DevGuard guard_(c->device);

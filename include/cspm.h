@@ -57,6 +57,10 @@ void cspm_destroy(cspm_ctx *ctx);
 const char *cspm_last_error(const cspm_ctx *ctx); /* ctx may be NULL: error of a failed cspm_create */
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
 int cspm_set_stream(cspm_ctx *ctx, void *hip_stream);
+/* the hipStream_t the ctx enqueues on (its own non-blocking stream unless cspm_set_stream replaced it): for callers that order their
+ * own work against it (events, torch.cuda.ExternalStream).  The batch driver keeps one ctx-owned stream per pair in flight: streams a
+ * framework hands out may share a hardware queue, and two pairs on one queue run one after the other. */
+int cspm_get_stream(cspm_ctx *ctx, void **hip_stream_out);
 int cspm_synchronize(cspm_ctx *ctx);
 
 /* ---- images: PreSSPC/PreCSPC/CSPatchMatch constructors' (l_img, r_img) ----------------------

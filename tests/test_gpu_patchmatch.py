@@ -313,7 +313,10 @@ def test_device_resident_io_stream_and_timing(gpu_ctx, small_pair):
     ctx = cs.StereoContext(0)
     stream = torch.cuda.Stream(device=dev)
     try:
+        own = ctx.stream_ptr()
+        assert own != 0
         ctx.set_stream(stream.cuda_stream)
+        assert ctx.stream_ptr() == stream.cuda_stream
         ctx.enable_timing(True)
         ctx.reset_timing()
         ctx.set_images_device(d_l.data_ptr(), d_r.data_ptr(), w, h, w * 3)
@@ -333,6 +336,7 @@ def test_device_resident_io_stream_and_timing(gpu_ctx, small_pair):
         assert all(t[k]["ms"] > 0 for k in ("grd", "init", "spatial", "view", "refine"))
         assert ctx.taps_per_view_pass() == sum(pc.taps(x, y) for y in range(h) for x in range(w))
         ctx.set_stream(0)
+        assert ctx.stream_ptr() == own  # back on the stream the context owns
     finally:
         ctx.close()
 
