@@ -46,6 +46,9 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_ROW_EXIT
 #define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
 #endif
+#ifndef CSPM_CELL_PAD
+#define CSPM_CELL_PAD 1    // cell tables with a pitch of a multiple of 256 bytes when they fit (no bank conflicts between table rows)
+#endif
 #ifndef CSPM_RANGE_MODE
 #define CSPM_RANGE_MODE 1  // cell mode with range-restricted tables on the levels whose full tables do not fit (0: general taps there)
 #endif
@@ -62,6 +65,16 @@ __device__ unsigned long long g_rowstat[16 * 8 * 8];
 // 1 some lane not interpolating everywhere, 2 range tables with the weight table, 3 without, 4 too many disparities for the LDS,
 // 5 sum of ND over the passes that took range mode, 6 sum of ND over the passes of bucket 4, 7 full cell mode
 __device__ unsigned long long g_rangestat[16 * 8 * 8];
+// wave cycles (s_memtime) by level: [level][0] rows of cell / range mode: total, [1] waiting for the row's strips, [2] table build,
+// [3] number of such rows; [4..7] the same for the DMA-staged general rows ([6] unused)
+__device__ unsigned long long g_rowtime[8 * 8];
+#define ROWTIME_NOW() __builtin_readcyclecounter()
+#define ROWTIME_ADD(slot, v) do { rowtime_acc[(slot) & 3] += (unsigned long long)(v); rowtime_base = (slot) & 4; } while (0)
+#define ROWTIME_FLUSH() do { if (lane == 0 && rowtime_acc[3]) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_rowtime[s * 8 + rowtime_base + k_], rowtime_acc[k_]); } while (0)
+#else
+#define ROWTIME_NOW() 0ull
+#define ROWTIME_ADD(slot, v) do { } while (0)
+#define ROWTIME_FLUSH() do { } while (0)
 #endif
 
 // Two wave-private LDS strips per window row (sized by strip_capacity / own_capacity, carved from the launch's dynamic LDS):
@@ -517,6 +530,10 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
                                              double c, bool exit_on, double need, bool dead_in) {
   constexpr int E = elem_size<SRC>();
   const int lane = ctx.lane;
+#ifdef CSPM_ROW_STATS
+  unsigned long long rowtime_acc[4] = {0, 0, 0, 0};
+  int rowtime_base = 0;
+#endif
   const Level &L = cd.lv[s];
   RowLevel A;
   A.W = L.W; A.n = cd.n; A.half = cd.half; A.Dm1 = L.D - 1;
@@ -592,11 +609,20 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
     const int ncent = cmax - cmin + 1, NQ = o_len;
     const int lds_room = wave_lds_bytes(ctx.cap, ctx.ocap) - 64;
     const int own_bytes = (NQ * 8 + 15) / 16 * 16 + (NQ * 4 + 15) / 16 * 16, wtab_bytes = ncent * A.n * 8 + ncent * 4;
-    int d_base = 1, ND = D;
+    // Table pitch.  A cell read is 64 lanes x 8 bytes at (table row of the lane's disparity, the lane's column): a half-wave is
+    // conflict-free when its 32 lanes hit 32 different bank pairs.  With ~64 centres (level 0) a half-wave holds 32 different columns:
+    // a pitch of a multiple of 32 entries (256 B) puts every table row on the same banks and no two lanes collide whatever their
+    // disparities (unpadded -- 98 entries, two bank pairs further per row -- a lane one disparity up collides with the lane two
+    // columns on).  With ~32 centres (level 1) two lanes share each column and may differ in disparity: the rows must NOT line up;
+    // a pitch = 16 mod 32 gives the 16 columns of a half-wave two disjoint halves of the banks for rows r and r+1.  Coarser levels
+    // (few columns per half-wave) are conflict-free as they are.  Padded when the LDS has the room.
+    const int NQP = ncent >= 48 ? (NQ + 31) / 32 * 32 : ncent >= 24 ? (NQ + 15) / 32 * 32 + 16 : NQ;
+    int d_base = 1, ND = D, pitch = NQ;
     bool cells_on = false, wtab = true, allv_level = false;
     if (CSPM_CELL_MODE && staged && D >= 2) {
       if ((NQ + D) * 16 + own_bytes + NQ * D * 8 + wtab_bytes <= lds_room) {
         cells_on = true;
+        if (CSPM_CELL_PAD && (NQ + D) * 16 + own_bytes + NQP * D * 8 + wtab_bytes <= lds_room) pitch = NQP;
 #ifdef CSPM_ROW_STATS
         if (lane == 0) atomicAdd(&g_rangestat[(ctx.stat_slot * 8 + s) * 8 + 7], 1ull);
 #endif
@@ -617,10 +643,13 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         f_lo = __builtin_amdgcn_readfirstlane(f_lo);
         f_hi = __builtin_amdgcn_readfirstlane(f_hi);
         const int nd = f_hi - f_lo + 1;
-        const int base_bytes = (NQ + nd) * 16 + own_bytes + NQ * nd * 8;
+        const int strip_bytes = (NQ + nd) * 16 + own_bytes, p2 = (NQ * 4 + 15) / 16 * 16;  // p2: a second colour run, see below
         if (__builtin_amdgcn_ballot_w64(!safe) == 0ull && (NQ + nd) <= kStripRegs * kWave) {
-          if (base_bytes + wtab_bytes <= lds_room) { cells_on = true; }
-          else if (!edge && base_bytes + (NQ * 4 + 15) / 16 * 16 <= lds_room) { cells_on = true; wtab = false; }  // + a second colour run, see below
+          // in order of preference: padded pitch with the weight table, padded without, unpadded with, unpadded without
+          if (CSPM_CELL_PAD && strip_bytes + NQP * nd * 8 + wtab_bytes <= lds_room) { cells_on = true; pitch = NQP; }
+          else if (CSPM_CELL_PAD && !edge && strip_bytes + p2 + NQP * nd * 8 <= lds_room) { cells_on = true; wtab = false; pitch = NQP; }
+          else if (strip_bytes + NQ * nd * 8 + wtab_bytes <= lds_room) { cells_on = true; }
+          else if (!edge && strip_bytes + p2 + NQ * nd * 8 <= lds_room) { cells_on = true; wtab = false; }
           if (cells_on) { d_base = f_lo; ND = nd; allv_level = true; }
         }
 #ifdef CSPM_ROW_STATS
@@ -643,7 +672,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       // Per-tap weights (!wtab) read the own colours of the CURRENT row while the next row's strips arrive: that run is double-buffered.
       const int p_bytes = (NQ * 4 + 15) / 16 * 16;
       const int off_g = c_len * 16, off_p = off_g + (NQ * 8 + 15) / 16 * 16, off_c = off_p + (wtab ? 1 : 2) * p_bytes;  // 16-byte DMA pieces
-      const int off_w = off_c + NQ * ND * 8, off_i = off_w + ncent * A.n * 8;
+      const int off_w = off_c + pitch * ND * 8, off_i = off_w + ncent * A.n * 8;
       const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
       const size_t Wp = (size_t)L.Wp;
       const char *g16 = uniform_ptr(reinterpret_cast<const char *>(L.px16[1 - VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + c_lo) * 16);
@@ -667,7 +696,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const int ipc_a = strip_a + off_i;
       if (wtab) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)(ipc_a + (cx - cmin) * 4) = Ip;
       CellRow C;
-      C.stride = NQ * 8;
+      C.stride = pitch * 8;
       C.adr_c = strip_a + off_c + (cx - cmin) * 8 - d_base * C.stride;  // table row k holds disparity d_base + k: f indexes row f - d_base
       C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
       C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
@@ -678,7 +707,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const int gcol0 = cmin - A.half;  // image column of table column q = 0
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
+        const unsigned long long rt0 = ROWTIME_NOW();
         dma_wait();  // the strips of row dy have landed; the taps of row dy-1 have read their tables
+        const unsigned long long rt1 = ROWTIME_NOW();
         // ---- cells[k][q], k = 0 .. ND-1 for disparities d_base .. d_base+ND-1: lane = table column q (its own element is read once),
         // disparities in batches of four (an entry is a chain of three dependent LDS round trips; the batch overlaps them).  The other
         // view's slot moves one slot per disparity and the table one row: every address in the batch is an immediate off two running bases.
@@ -745,6 +776,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const double rowterm = b * (double)qy + c;  // q_disp_y, :155
         double Rsum;
         dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go
+        const unsigned long long rt2 = ROWTIME_NOW();
         C.adr_p = strip_a + off_p + par * p_bytes + (cx - cmin) * 4;  // this row's own colours (per-tap weights)
         if (!wtab) par ^= 1;
         if (dy < dy_hi) issue(par);
@@ -763,8 +795,16 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           Rsum = cell_row_taps<true, false>(A, lut, C, a, rowterm, qx0_d);
         }
         tree.push(dy, Rsum);
-        if (all_rejected(Rsum)) { dma_wait(); return __builtin_inf(); }
+#ifdef CSPM_ROW_STATS
+        {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long rt3 = ROWTIME_NOW();
+          ROWTIME_ADD(0, rt3 - rt0); ROWTIME_ADD(1, rt1 - rt0); ROWTIME_ADD(2, rt2 - rt1); ROWTIME_ADD(3, 1);
+        }
+#endif
+        if (all_rejected(Rsum)) { dma_wait(); ROWTIME_FLUSH(); return __builtin_inf(); }
       }
+      ROWTIME_FLUSH();
       return tree.total(dy_hi + 1);
     }
   }
@@ -798,7 +838,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       int par = 0;
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
+        const unsigned long long rt0 = ROWTIME_NOW();
         dma_wait();  // row dy has landed; the reads of row dy-1 (the buffer the next DMA overwrites) have returned
+        const unsigned long long rt1 = ROWTIME_NOW();
         if (dy < dy_hi) issue(lds0 + (unsigned)(par ? 0 : set));
         RowSrc Rr = R;
         const int boff = par ? set : 0;
@@ -818,9 +860,17 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           Rsum = row_taps<SRC, VIEW, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
         }
         tree.push(dy, Rsum);
-        if (all_rejected(Rsum)) { dma_wait(); return __builtin_inf(); }
+#ifdef CSPM_ROW_STATS
+        {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long rt3 = ROWTIME_NOW();
+          ROWTIME_ADD(4, rt3 - rt0); ROWTIME_ADD(5, rt1 - rt0); ROWTIME_ADD(7, 1);
+        }
+#endif
+        if (all_rejected(Rsum)) { dma_wait(); ROWTIME_FLUSH(); return __builtin_inf(); }
         par ^= 1;
       }
+      ROWTIME_FLUSH();
       return tree.total(dy_hi + 1);
     }
   }

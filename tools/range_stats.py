@@ -32,3 +32,13 @@ stats("init")
 for it in range(3):
     ctx.pm_spatial(it, seed=12345); ctx.pm_view(it, seed=12345); stats(f"view {it}")
     ctx.pm_refine(it, seed=12345); stats(f"refine {it}")
+# wave cycles per row by level (s_memtime, 100 MHz constant clock on gfx950: 1 tick = 10 ns), summed over the whole run above
+L.cspm_debug_rowtime.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+t = (C.c_ulonglong * 64)()
+L.cspm_debug_rowtime(t, 1)
+for s in range(5):
+    g = [t[s * 8 + k] for k in range(8)]
+    if g[3]:
+        print(f"level {s}: table rows {g[3]:9d}: {g[0] / g[3]:7.1f} ticks per row, waiting for the strips {g[1] / g[3]:6.1f}, table build {g[2] / g[3]:6.1f}")
+    if g[7]:
+        print(f"level {s}: general DMA rows {g[7]:9d}: {g[4] / g[7]:7.1f} ticks per row, waiting for the strips {g[5] / g[7]:6.1f}")
