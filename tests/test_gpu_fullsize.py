@@ -128,7 +128,7 @@ def test_c2_whole_pipeline_bit_exact(gpu_ctx):
     gpu_ctx.patchmatch(3, seed=12345, schedule=0)
     pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
     pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
-    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE, wavefront=True)  # the oracle's sweep as a wavefront: identical, faster
     for v in (0, 1):
         npar, cost = gpu_ctx.get_planes(v)
         P = pm.planes(v)
