@@ -89,8 +89,7 @@ struct cspm_ctx {
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   unsigned long long *d_maxkeys = nullptr;
   int row_claim = -1;  // row kernels: -1 = claimed column bands for launches of several rounds (default), 0 / 1 = never / always (env CSPM_ROW_CLAIM, tests)
-  unsigned int *d_rowq = nullptr;  // row kernels: a ring of claim-counter sets (8 counters each), one set per launch (cspm_rows.h row_item)
-  int rowq_next = 0;
+  unsigned int *d_rowq = nullptr;  // row kernels: the eight claim counters of a launch that claims its items (cspm_rows.h row_item)
   // plane field
   bool field_alloc = false;
   bool field_consistent = false;  // every min_cost was computed from the stored plane by this cost object (not by cspm_set_planes)
@@ -223,8 +222,8 @@ inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cos
 inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }
 inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * wave_lds_bytes(row_cap(c), row_ocap(c)); }
 
-// the claim counters of the next row-kernel launch, zeroed on the stream right before it; none for a launch of interleaved row blocks
-constexpr int kRowQueueSets = 1;
+// the claim counters of the next row-kernel launch, zeroed on the stream right before it (launches of a context are serial on its
+// stream: one set suffices); none for a launch of interleaved row blocks
 inline RowQueue next_row_queue(cspm_ctx *c, int views) {
   if (!row_claimed(c, views)) return RowQueue{nullptr};
   (void)hipMemsetAsync(c->d_rowq, 0, 8 * sizeof(unsigned int), c->stream);
@@ -552,7 +551,7 @@ int ensure_field(cspm_ctx *c) {
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
   }
   if ((rc = dalloc(c, &c->d_todo, 2 * n + 2, nullptr))) return rc;
-  if ((rc = dalloc(c, &c->d_rowq, 8 * kRowQueueSets, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->d_rowq, 8, nullptr))) return rc;
   // persistent sweep state: control words, per-pixel granules (tag zero = never written), diagonal start table
   if ((rc = dalloc(c, &c->d_sweep_ctrl, 2 + kSweepMaxBands, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, (2 + kSweepMaxBands) * sizeof(unsigned int), c->stream));

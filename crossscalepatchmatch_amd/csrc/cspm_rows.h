@@ -707,9 +707,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       const int gcol0 = cmin - A.half;  // image column of table column q = 0
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
-        const unsigned long long rt0 = ROWTIME_NOW();
+        [[maybe_unused]] const unsigned long long rt0 = ROWTIME_NOW();
         dma_wait();  // the strips of row dy have landed; the taps of row dy-1 have read their tables
-        const unsigned long long rt1 = ROWTIME_NOW();
+        [[maybe_unused]] const unsigned long long rt1 = ROWTIME_NOW();
         // ---- cells[k][q], k = 0 .. ND-1 for disparities d_base .. d_base+ND-1: lane = table column q (its own element is read once),
         // disparities in batches of four (an entry is a chain of three dependent LDS round trips; the batch overlaps them).  The other
         // view's slot moves one slot per disparity and the table one row: every address in the batch is an immediate off two running bases.
@@ -776,7 +776,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const double rowterm = b * (double)qy + c;  // q_disp_y, :155
         double Rsum;
         dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go
-        const unsigned long long rt2 = ROWTIME_NOW();
+        [[maybe_unused]] const unsigned long long rt2 = ROWTIME_NOW();
         C.adr_p = strip_a + off_p + par * p_bytes + (cx - cmin) * 4;  // this row's own colours (per-tap weights)
         if (!wtab) par ^= 1;
         if (dy < dy_hi) issue(par);
@@ -838,9 +838,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       int par = 0;
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
-        const unsigned long long rt0 = ROWTIME_NOW();
+        [[maybe_unused]] const unsigned long long rt0 = ROWTIME_NOW();
         dma_wait();  // row dy has landed; the reads of row dy-1 (the buffer the next DMA overwrites) have returned
-        const unsigned long long rt1 = ROWTIME_NOW();
+        [[maybe_unused]] const unsigned long long rt1 = ROWTIME_NOW();
         if (dy < dy_hi) issue(lds0 + (unsigned)(par ? 0 : set));
         RowSrc Rr = R;
         const int boff = par ? set : 0;
