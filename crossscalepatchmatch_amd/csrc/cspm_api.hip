@@ -42,10 +42,10 @@ struct DevGuard {
 
 // what the buffers of a cost object were sized for: an identical request reuses them (no hipMalloc / hipFree per pair)
 struct CostKey {
-  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1, with_pairs = 0;
+  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1, with_pairs = 0, with_cvol = 0;
   bool operator==(const CostKey &o) const {
     return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind &&
-           with_pairs == o.with_pairs;
+           with_pairs == o.with_pairs && with_cvol == o.with_cvol;
   }
 };
 enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2, kKindImg = 3 };
@@ -87,6 +87,8 @@ struct cspm_ctx {
   long long opt_sweep_pairs = 0;   // CSPM_OPT_SWEEP_PAIRS: 0 = never (default: measured no faster), 1 = when they fit
   long long sweep_pairs_limit = 4LL << 30;  // bytes of paired-cell volumes a context may hold (env CSPM_SWEEP_PAIRS_MAX_MB)
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
+  long long opt_table_volumes = 1;          // CSPM_OPT_TABLE_VOLUMES: device-cell volumes for the row engine's DMA-filled tables, when they fit
+  long long table_volumes_limit = 48LL << 30; // bytes of such volumes a context may hold (env CSPM_TABLE_VOLUMES_MAX_MB): 288 GB of HBM per GPU, a few contexts in flight
   unsigned long long *d_maxkeys = nullptr;
   int row_claim = -1;  // row kernels: -1 = claimed column bands for launches of several rounds (default), 0 / 1 = never / always (env CSPM_ROW_CLAIM, tests)
   unsigned int *d_rowq = nullptr;  // row kernels: the eight claim counters of a launch that claims its items (cspm_rows.h row_item)
@@ -376,7 +378,8 @@ void launch_pyramid(cspm_ctx *c) {
 // allocate the (padded) pyramid images, the per-kind side arrays (gradients / census codes) and, when `with_vol`, the
 // cost volumes; fill Cost (everything except gradients / volume contents / max_cost).  An identical request (same
 // image size, max_dis, window, levels, kind, volumes) reuses every buffer: no allocator call, no host synchronisation.
-int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind, bool want_pairs = false) {
+int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg_lambda, bool with_vol, int kind, bool want_pairs = false,
+               bool want_cvol = false) {
   if (!c->img0[0]) return fail(c, CSPM_ERR_STATE, "cspm_set_images must precede cost construction");
   if (max_dis < 1 || wnd_size < 1 || wnd_size > kMaxWnd || scale_num < 0 || scale_num > CSPM_MAX_LEVELS)
     return fail(c, CSPM_ERR_ARG, "bad max_dis / wnd_size / scale_num");
@@ -395,9 +398,25 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     }
     with_pairs = fits && bytes <= c->sweep_pairs_limit;
   }
+  // device-cell volumes for the row engine's DMA-filled tables: C3 1.2 GB, a 3000 x 2000 D = 256 pair 30 GB (each level's volume
+  // must stay below 4 GiB per 16 disparities: the DMA's 32-bit offsets span the slabs of one table)
+  bool with_cvol = false;
+  const int cvpad_all = wnd_size / 2 + 2;
+  if (want_cvol) {
+    long long bytes = 0;
+    bool fits32 = true;
+    int W = c->W, H = c->H, D = max_dis;
+    for (int s = 0; s < (scale_num > 0 ? scale_num : 1); ++s) {
+      if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
+      bytes += 2LL * (D + 1) * H * (W + 2 * cvpad_all) * 8;
+      if ((long long)H * (W + 2 * cvpad_all) * 8 * std::min(D + 1, 64) >= (1LL << 32)) fits32 = false;  // a table's slabs within 32-bit offsets
+    }
+    with_cvol = fits32 && bytes <= c->table_volumes_limit;
+  }
   CostKey key;
   key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
   key.with_pairs = with_pairs;
+  key.with_cvol = with_cvol;
   const bool reuse = c->cost_alloc && key == c->cost_key;
   if (!reuse) free_cost(c);
   Cost &cd = c->cost;
@@ -437,6 +456,16 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         L.grd[v] = nullptr;
         L.vol[v] = nullptr;
         L.vol2[v] = nullptr;
+        L.cvol[v] = nullptr;
+        L.cvpad = cvpad_all;
+        L.cvW = W + 2 * cvpad_all;
+        if (with_cvol) {
+          double *cv;
+          const size_t ncv = (size_t)(D + 1) * H * L.cvW + 64;  // + slack: the last DMA piece of the last row may run 8 bytes over
+          if ((rc = dalloc(c, &cv, ncv, &c->cost_allocs))) return rc;
+          HIPCHK(c, hipMemsetAsync(cv, 0, ncv * sizeof(double), c->stream));  // the pad columns stay 0.0; the image columns are rewritten per pair
+          L.cvol[v] = cv;
+        }
         if (with_pairs) {
           double2 *v2;
           if ((rc = dalloc(c, &v2, (size_t)std::max(D, 2) * px, &c->cost_allocs))) return rc;  // slabs 0 .. D-1; a level with D < 2 is only ever addressed (slab 1), never used
@@ -899,6 +928,8 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_ROW_CLAIM")) c->row_claim = atoi(e) < 0 ? -1 : (atoi(e) ? 1 : 0);
   if (const char *e = getenv("CSPM_SWEEP_BANDS")) c->sweep_bands = std::max(1, std::min(kSweepMaxBands, atoi(e)));
   if (const char *e = getenv("CSPM_SWEEP_PAIRS")) c->opt_sweep_pairs = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_TABLE_VOLUMES")) c->opt_table_volumes = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_TABLE_VOLUMES_MAX_MB")) c->table_volumes_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -1011,6 +1042,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_GRD_VOLUMES: c->opt_grd_volumes = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_RASTER_LAUNCHES: c->opt_raster_launches = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS: c->opt_sweep_pairs = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_TABLE_VOLUMES: c->opt_table_volumes = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -1027,6 +1059,8 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_SWEEP_TIMEOUT_MS: *value = c->sweep_timeout_ms; return CSPM_OK;
     case CSPM_OPT_SWEEP_FALLBACKS: *value = c->sweep_fallbacks; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS: *value = c->opt_sweep_pairs; return CSPM_OK;
+    case CSPM_OPT_TABLE_VOLUMES: *value = c->opt_table_volumes; return CSPM_OK;
+    case CSPM_OPT_TABLE_VOLUMES_ACTIVE: *value = (c->cost_alloc && c->cost.lv[0].cvol[0]) ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     default: return fail(c, CSPM_ERR_ARG, "unknown option");
   }
@@ -1037,7 +1071,8 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   const bool with_vol = c->opt_grd_volumes != 0;
-  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindGrd, !with_vol && c->opt_sweep_pairs != 0);
+  int rc = alloc_cost(c, max_dis, wnd_size, scale_num, reg_lambda, with_vol, kKindGrd, !with_vol && c->opt_sweep_pairs != 0,
+                      !with_vol && c->opt_table_volumes != 0);
   if (rc) return rc;
   Cost &cd = c->cost;
   // gradients of both views per level (grd_cc.cpp:70-77); then the GRD cells of both views
@@ -1061,7 +1096,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
       Timed t(c, CSPM_K_GRD, 0);
       hipLaunchKernelGGL((k_grd_volume<SrcU32, true>), dim3(stride_grid(cells)), dim3(256), 0, c->stream, SrcU32{L.pix[0], L.Wp, L.pad},
                          SrcU32{L.pix[1], L.Wp, L.pad}, L.grd[0], L.grd[1], L.Wp, L.pad, L.W, L.H, 0, L.D + 1, v,
-                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s, (double2 *)L.vol2[v]);
+                         (double *)L.vol[v], c->d_maxkeys + v * CSPM_MAX_LEVELS + s, (double2 *)L.vol2[v], (double *)L.cvol[v], L.cvW, L.cvpad);
     }
   }
   HIPCHK(c, hipGetLastError());

@@ -63,6 +63,10 @@ struct Level {
   const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
   const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only
   const double *vol[2];   // cost_vol_[v][s]: (D+1) slabs of H*W doubles, d-major; null when fused
+  const double *cvol[2];  // fused GRD only, when it fits the context's budget: the level's DEVICE cells (the bits of grd_cell()) as a volume of
+                          // D+1 slabs x H rows x cvW columns, image column x at index cvpad + x (pad columns hold 0.0: only ever read under
+                          // weight 0) -- the row engine's cell tables are then filled by LDS-DMA instead of being computed (cspm_rows.h)
+  int cvW, cvpad;
   const double2 *vol2[2]; // kSrcVol2: D slabs of H*W pairs {cell(d), cell(d+1)} of the DEVICE cells (same bits as grd_cell()); null unless built
   double wgt;             // scale_wgt_[s]
 };

@@ -451,7 +451,8 @@ __global__ void k_gradient(Src s, int W, int H, int gWp, int gpad, double *__res
 template <class Src, bool DEV>
 __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *__restrict__ lG, const double *__restrict__ rG,
                                                     int gWp, int gpad, int W, int H, int d0, int nd, int right_view,
-                                                    double *__restrict__ vol, unsigned long long *max_key, double2 *__restrict__ vol2 = nullptr) {
+                                                    double *__restrict__ vol, unsigned long long *max_key, double2 *__restrict__ vol2 = nullptr,
+                                                    double *__restrict__ cvol = nullptr, int cvW = 0, int cvpad = 0) {
   const long long slab = (long long)W * H;
   const long long cells = slab * nd;
   double best = -1.7976931348623157e308;
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(256) void k_grd_volume(Src l, Src r, const double *
     grdDiff = grdDiff > 2.0 ? 2.0 : grdDiff;    // TAU_GRD
     cost = DEV ? __builtin_fma(1 - 0.1, grdDiff, 0.1 * clrDiff) : 0.1 * clrDiff + (1 - 0.1) * grdDiff;  // ALPHA
     if (vol) vol[i] = cost;
+    if (cvol) cvol[((size_t)d * H + y) * cvW + cvpad + x] = cost;  // the padded volume the row engine's tables are DMA-filled from
     if (vol2) {  // the sweep's paired cells (kSrcVol2): slab d holds {cell(d), cell(d+1)}, d = 0 .. nd-2 (d0 == 0)
       if (d + 1 < nd) vol2[i].x = cost;
       if (d >= 1) vol2[i - slab].y = cost;

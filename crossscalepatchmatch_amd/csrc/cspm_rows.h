@@ -46,6 +46,15 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_ROW_EXIT
 #define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
 #endif
+#ifndef CSPM_TABLE_DMA
+#define CSPM_TABLE_DMA 1   // cell tables filled by LDS-DMA from the level's device-cell volume when the cost object carries one (0: always computed)
+#endif
+#ifndef CSPM_TABLE_CLUSTERS
+#define CSPM_TABLE_CLUSTERS 1     // ... and with the rows of TWO disparity clusters when a wave's lanes lie on two surfaces
+#endif
+#ifndef CSPM_TABLE_DMA_SINGLE
+#define CSPM_TABLE_DMA_SINGLE 1   // ... also with ONE table buffer where two do not fit (0: compute the table then)
+#endif
 #ifndef CSPM_CELL_PAD
 #define CSPM_CELL_PAD 1    // cell tables with a pitch of a multiple of 256 bytes when they fit (no bank conflicts between table rows)
 #endif
@@ -618,15 +627,21 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
     // (few columns per half-wave) are conflict-free as they are.  Padded when the LDS has the room.
     const int NQP = ncent >= 48 ? (NQ + 31) / 32 * 32 : ncent >= 24 ? (NQ + 15) / 32 * 32 + 16 : NQ;
     int d_base = 1, ND = D, pitch = NQ;
-    bool cells_on = false, wtab = true, allv_level = false;
+    bool cells_on = false, wtab = true, allv_level = false, tdma = false;
+    // two clusters of disparities (a wave across a depth discontinuity): lanes of cluster B use table rows nd_a .. with base b_lo
+    int nd_a = 0, b_lo = 0;
+    bool lane_b = false;
+    int tbuf = 2;  // DMA-filled tables: 2 = the next row's table lands while this row's taps run; 1 = it is fetched after them
+    const int p2 = (NQ * 4 + 15) / 16 * 16;  // a run of own colours, in 16-byte DMA pieces
     if (CSPM_CELL_MODE && staged && D >= 2) {
-      if ((NQ + D) * 16 + own_bytes + NQ * D * 8 + wtab_bytes <= lds_room) {
-        cells_on = true;
-        if (CSPM_CELL_PAD && (NQ + D) * 16 + own_bytes + NQP * D * 8 + wtab_bytes <= lds_room) pitch = NQP;
-#ifdef CSPM_ROW_STATS
-        if (lane == 0) atomicAdd(&g_rangestat[(ctx.stat_slot * 8 + s) * 8 + 7], 1ull);
-#endif
-      } else if (CSPM_RANGE_MODE && D < 512 && dy_lo <= dy_hi) {
+      const bool full_fits = (NQ + D) * 16 + own_bytes + NQ * D * 8 + wtab_bytes <= lds_room;
+      // DMA-filled tables (Level::cvol): the device cells of this level are in memory, a table row is a run of a volume row
+      const bool have_cvol = CSPM_TABLE_DMA && L.cvol[VIEW] != nullptr;
+      // the range test, where it can matter: the full table does not fit, or the tables could be DMA-filled (two of them must fit)
+      bool range_ok = false;
+      int f_lo = 1, f_hi = 1;
+      int fl_lane = 1, fh_lane = 1;  // the lane's own interval of integer disparities (valid when range_ok)
+      if ((!full_fits || have_cvol) && CSPM_RANGE_MODE && D < 512 && dy_lo <= dy_hi) {
         const int jl = (A.n - 1) % kRowMod;
         const double rt0 = b * (double)(cy - A.half + dy_lo) + c, rt1 = b * (double)(cy - A.half + dy_hi) + c;  // q_disp_y of the first / last row
         const double q00 = tap_disp(a, 0.0, group_disp(a, qx0_d, rt0)), q01 = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rt0));
@@ -634,7 +649,8 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const double qmin = __builtin_fmin(__builtin_fmin(q00, q01), __builtin_fmin(q10, q11));
         const double qmax = __builtin_fmax(__builtin_fmax(q00, q01), __builtin_fmax(q10, q11));
         const bool safe = (qmin >= 1.0 + 0x1p-20) & (qmax <= (double)D - 0x1p-20);  // false for NaN
-        int f_lo = safe ? (int)(qmin - 0x1p-20) : 1, f_hi = safe ? (int)(qmax + 0x1p-20) + 1 : 1;
+        f_lo = fl_lane = safe ? (int)(qmin - 0x1p-20) : 1;
+        f_hi = fh_lane = safe ? (int)(qmax + 0x1p-20) + 1 : 1;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
           f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
@@ -642,9 +658,68 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         }
         f_lo = __builtin_amdgcn_readfirstlane(f_lo);
         f_hi = __builtin_amdgcn_readfirstlane(f_hi);
-        const int nd = f_hi - f_lo + 1;
-        const int strip_bytes = (NQ + nd) * 16 + own_bytes, p2 = (NQ * 4 + 15) / 16 * 16;  // p2: a second colour run, see below
-        if (__builtin_amdgcn_ballot_w64(!safe) == 0ull && (NQ + nd) <= kStripRegs * kWave) {
+        range_ok = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
+      }
+      const int nd = f_hi - f_lo + 1;
+      if (have_cvol) {
+        // two tables (the DMA of row dy+1 lands while the taps of row dy read theirs), two runs of own colours, the weight table
+        // where it fits; table rows of an even number of entries (16-byte pieces).  At most 8 DMA instructions per table.
+        const int NQE = (NQ + 1) & ~1, NQD = NQP > NQE ? NQP : NQE;
+        auto fits = [&](int nb, int n_, int pit, bool wt) { return nb * n_ * pit * 8 + 2 * p2 + (wt ? wtab_bytes : 0) <= lds_room && n_ * (pit / 2) <= 12 * kWave; };
+        // in order of preference: two tables before one (with one, the fetch of the next row's table waits for this row's taps: its
+        // latency is hidden by the other waves of the SIMD only), padded pitch before unpadded, the weight table before per-tap weights
+        for (int nb = 2; nb >= 1 && !tdma; --nb) {
+          if (range_ok) {
+            if (CSPM_CELL_PAD && fits(nb, nd, NQD, true)) { tdma = true; pitch = NQD; }
+            else if (CSPM_CELL_PAD && !edge && fits(nb, nd, NQD, false)) { tdma = true; pitch = NQD; wtab = false; }
+            else if (fits(nb, nd, NQE, true)) { tdma = true; pitch = NQE; }
+            else if (!edge && fits(nb, nd, NQE, false)) { tdma = true; pitch = NQE; wtab = false; }
+            if (tdma) { cells_on = true; d_base = f_lo; ND = nd; allv_level = true; tbuf = nb; }
+          }
+          if (!tdma && full_fits) {  // every disparity of a coarse level
+            if (CSPM_CELL_PAD && fits(nb, D, NQD, true)) { tdma = true; pitch = NQD; }
+            else if (fits(nb, D, NQE, true)) { tdma = true; pitch = NQE; }
+            if (tdma) { cells_on = true; tbuf = nb; }
+          }
+          if (!CSPM_TABLE_DMA_SINGLE) break;
+        }
+        // Two surfaces in one wave (a depth discontinuity: 20-35 % of the level passes at levels 0-1 once the planes have settled):
+        // the lanes' disparity intervals fall into two narrow clusters far apart.  Cut at the middle of the wave's span; when
+        // no lane's interval straddles the cut, the table holds the rows of cluster A and then those of cluster B, and a lane
+        // addresses the rows of its own cluster.
+        if (CSPM_TABLE_CLUSTERS && !tdma && range_ok && nd > 2) {
+          const int cut = (f_lo + f_hi + 1) / 2;
+          const bool in_a = fh_lane < cut, in_b = fl_lane >= cut;
+          if (__builtin_amdgcn_ballot_w64(!(in_a | in_b)) == 0ull) {
+            int a_hi = in_a ? fh_lane : f_lo, bl = in_b ? fl_lane : f_hi;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+              a_hi = max(a_hi, __shfl_xor(a_hi, off, kWave));
+              bl = min(bl, __shfl_xor(bl, off, kWave));
+            }
+            a_hi = __builtin_amdgcn_readfirstlane(a_hi);
+            bl = __builtin_amdgcn_readfirstlane(bl);
+            const int na = a_hi - f_lo + 1, nb_ = f_hi - bl + 1, nt = na + nb_;
+            const bool span_ok = (unsigned long long)(f_hi - f_lo + 1) * (unsigned long long)L.H * (unsigned long long)L.cvW * 8ull < (1ull << 32);  // 32-bit DMA offsets
+            if (nt < nd && span_ok) {
+              for (int nb = 2; nb >= 1 && !tdma; --nb) {
+                if (CSPM_CELL_PAD && fits(nb, nt, NQD, true)) { tdma = true; pitch = NQD; }
+                else if (CSPM_CELL_PAD && !edge && fits(nb, nt, NQD, false)) { tdma = true; pitch = NQD; wtab = false; }
+                else if (fits(nb, nt, NQE, true)) { tdma = true; pitch = NQE; }
+                else if (!edge && fits(nb, nt, NQE, false)) { tdma = true; pitch = NQE; wtab = false; }
+                if (tdma) { cells_on = true; d_base = f_lo; ND = nt; allv_level = true; tbuf = nb; nd_a = na; b_lo = bl; lane_b = in_b; }
+                if (!CSPM_TABLE_DMA_SINGLE) break;
+              }
+            }
+          }
+        }
+      }
+      if (!tdma) {
+        if (full_fits) {
+          cells_on = true;
+          if (CSPM_CELL_PAD && (NQ + D) * 16 + own_bytes + NQP * D * 8 + wtab_bytes <= lds_room) pitch = NQP;
+        } else if (range_ok && (NQ + nd) <= kStripRegs * kWave) {
+          const int strip_bytes = (NQ + nd) * 16 + own_bytes;
           // in order of preference: padded pitch with the weight table, padded without, unpadded with, unpadded without
           if (CSPM_CELL_PAD && strip_bytes + NQP * nd * 8 + wtab_bytes <= lds_room) { cells_on = true; pitch = NQP; }
           else if (CSPM_CELL_PAD && !edge && strip_bytes + p2 + NQP * nd * 8 <= lds_room) { cells_on = true; wtab = false; pitch = NQP; }
@@ -652,16 +727,144 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           else if (!edge && strip_bytes + p2 + NQ * nd * 8 <= lds_room) { cells_on = true; wtab = false; }
           if (cells_on) { d_base = f_lo; ND = nd; allv_level = true; }
         }
+      }
 #ifdef CSPM_ROW_STATS
-        if (lane == 0) {
-          unsigned long long *g = &g_rangestat[(ctx.stat_slot * 8 + s) * 8];
+      if (lane == 0) {
+        unsigned long long *g = &g_rangestat[(ctx.stat_slot * 8 + s) * 8];
+        if (cells_on && !allv_level) atomicAdd(&g[7], 1ull);
+        else {
           atomicAdd(&g[0], 1ull);
-          if (__builtin_amdgcn_ballot_w64(!safe) != 0ull) atomicAdd(&g[1], 1ull);
+          if (!range_ok) atomicAdd(&g[1], 1ull);
           else if (cells_on) { atomicAdd(&g[wtab ? 2 : 3], 1ull); atomicAdd(&g[5], (unsigned long long)nd); }
           else { atomicAdd(&g[4], 1ull); atomicAdd(&g[6], (unsigned long long)nd); }
         }
-#endif
       }
+#endif
+    }
+    // wgts[c][j] = exp(-|I_centre(c) - I(c + j)| / 10), 0 for a column outside the image: lane = window column j, one centre per trip
+    // (its colour is one broadcast read); the row's own colours at LDS address `adr_pix`, the centres' colours at `adr_ipc`
+    auto build_wtab = [&](int adr_pix, int adr_ipc, int adr_wgt) {
+      const int gcol0 = cmin - A.half;  // image column of table column q = 0
+      for (int j0 = 0; j0 < A.n; j0 += kWave) {
+        const int j = j0 + lane;
+        const bool jon = j < A.n;
+        const int js = jon ? j : 0;
+        int adr_p = adr_pix + js * 4, adr_o = adr_wgt + js * 8;
+        int col = gcol0 + js;
+        constexpr int U = 4;
+        for (int c0 = 0; c0 < ncent; c0 += U) {
+          uint32_t ic[U], pq[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            ic[u] = lds_ld<uint32_t>(adr_ipc + (c0 + u) * 4);  // c0 + u < ncent + U: inside the wave's LDS, the value is not used beyond ncent
+            pq[u] = lds_ld<uint32_t>(adr_p + u * 4);
+          }
+          double w[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            int sad = (int)__builtin_amdgcn_sad_u8(ic[u], pq[u], 0u);
+            sad = ((unsigned)(col + u) < (unsigned)A.W) ? sad : kLutZero;  // outside the image: weight 0, the tap adds +0.0
+            w[u] = lut.w[sad];
+          }
+          int ao = adr_o;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (jon && c0 + u < ncent) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)ao = w[u];
+            ao += A.n * 8;
+          }
+          adr_p += U * 4; adr_o = ao; col += U;
+        }
+      }
+    };
+    if (cells_on && tdma) {
+      // ---- tables filled by LDS-DMA from the level's device-cell volume.  LDS of the wave: table 0 | table 1 | colours 0 | colours 1
+      // [| weights | centre colours].  A table is ND rows of `pitch` entries = pitch / 2 sixteen-byte pieces, NQE / 2 of them carrying
+      // columns; piece e of the table (row e / ppr, piece e % ppr) is moved by lane e % 64 of DMA instruction e / 64.
+      const int tbytes = ND * pitch * 8, ppr = pitch / 2, used = (NQ + 1) / 2, npiece = ND * ppr;
+      const int off_p = tbuf * tbytes, off_w = off_p + 2 * p2, off_i = off_w + ncent * A.n * 8;
+      const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane(strip_a);
+      const unsigned inv = ((1u << 20) + (unsigned)ppr - 1u) / (unsigned)ppr;  // e / ppr == (e * inv) >> 20 for e < 2048, ppr <= 64
+      const size_t Wp = (size_t)L.Wp;
+      const unsigned rowB = (unsigned)L.cvW * 8u, slabB = (unsigned)L.H * rowB;
+      const char *cv = uniform_ptr(reinterpret_cast<const char *>(L.cvol[VIEW]) + (size_t)d_base * slabB + (size_t)(cy - A.half + dy_lo) * rowB +
+                                   (size_t)(L.cvpad + cmin - A.half) * 8);
+      const char *gp = uniform_ptr(reinterpret_cast<const char *>(L.pix[VIEW]) + ((size_t)(cy - A.half + dy_lo) * Wp + o_lo) * 4);
+      const int p_p16 = (NQ * 4 + 15) / 16;
+      auto issue_tab = [&](int tb) {  // the table of the next row into table buffer tb
+        const unsigned dst = lds0 + (unsigned)(tb * tbytes);
+        for (int i = 0; i * kWave < npiece; ++i) {
+          const unsigned e = (unsigned)(lane + i * kWave);
+          const unsigned k = (e * inv) >> 20, pc = e - k * (unsigned)ppr;
+          const unsigned dk = (nd_a > 0 && (int)k >= nd_a) ? k + (unsigned)(b_lo - d_base - nd_a) : k;  // table row k holds disparity d_base + dk
+          if (e < (unsigned)npiece && pc < (unsigned)used) dma_b128(cv, dk * slabB + pc * 16u, dst + (unsigned)i * 1024u);
+        }
+        cv += rowB;
+      };
+      auto issue_pix = [&](int pb) {  // the own colours of the next row into colour run pb
+        if (lane < p_p16) dma_b128(gp, (unsigned)lane * 16u, lds0 + (unsigned)(off_p + pb * p2));
+        gp += Wp * 4;
+      };
+      dma_wait();  // the previous level's LDS reads have returned
+      issue_pix(0);
+      issue_tab(0);
+      const int ipc_a = strip_a + off_i;
+      if (wtab) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(unsigned)(ipc_a + (cx - cmin) * 4) = Ip;
+      CellRow C;
+      C.stride = pitch * 8;
+      C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
+      C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
+      asm volatile("" : "+v"(C.adr_w2));
+      asm volatile("" : "+v"(C.adr_w3));
+      asm volatile("" : "+v"(C.adr_w4));
+      C.Ip = Ip;
+      // table row k holds disparity d_base + k (cluster B: b_lo + k - nd_a): f indexes row f - d_base (f - b_lo + nd_a)
+      const int adr_c0 = strip_a + (cx - cmin) * 8 - (lane_b ? b_lo - nd_a : d_base) * C.stride;
+      int par = 0;
+      for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+        const int qy = cy - A.half + dy;
+        [[maybe_unused]] const unsigned long long rt0 = ROWTIME_NOW();
+        dma_wait();  // the table and the colours of row dy have landed; the taps of row dy-1 (the other table) have returned
+        [[maybe_unused]] const unsigned long long rt1 = ROWTIME_NOW();
+        if (dy < dy_hi) {
+          issue_pix(par ^ 1);
+          if (tbuf == 2) issue_tab(par ^ 1);
+        }
+        C.adr_c = adr_c0 + (tbuf == 2 ? par * tbytes : 0);
+        C.adr_p = strip_a + off_p + par * p2 + (cx - cmin) * 4;
+        if (wtab) build_wtab(strip_a + off_p + par * p2, ipc_a, strip_a + off_w);
+        const double rowterm = b * (double)qy + c;  // q_disp_y, :155
+        double Rsum;
+        if (wtab) {
+          bool allv = allv_level;
+          if (!allv_level) {  // full tables: decide per row whether every tap interpolates
+            const int jl = (A.n - 1) % kRowMod;
+            const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+            const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+            const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+            const bool safe = (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+            allv = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
+          }
+          Rsum = allv ? cell_row_taps<true, true>(A, lut, C, a, rowterm, qx0_d) : cell_row_taps<false, true>(A, lut, C, a, rowterm, qx0_d);
+        } else {
+          Rsum = cell_row_taps<true, false>(A, lut, C, a, rowterm, qx0_d);
+        }
+        tree.push(dy, Rsum);
+#ifdef CSPM_ROW_STATS
+        {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long rt3 = ROWTIME_NOW();
+          ROWTIME_ADD(0, rt3 - rt0); ROWTIME_ADD(1, rt1 - rt0); ROWTIME_ADD(3, 1);
+        }
+#endif
+        if (all_rejected(Rsum)) { dma_wait(); ROWTIME_FLUSH(); return __builtin_inf(); }
+        if (tbuf == 1 && dy < dy_hi) {  // one table: the taps' reads have to be back before the next row's table may land on it
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issue_tab(0);
+        }
+        par ^= 1;
+      }
+      ROWTIME_FLUSH();
+      return tree.total(dy_hi + 1);
     }
     if (cells_on) {
       // strip window of the table's disparities (padded columns): slot(q, d) = q + (d_base + ND - 1) - d for the left view,
@@ -704,7 +907,6 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       asm volatile("" : "+v"(C.adr_w3));
       asm volatile("" : "+v"(C.adr_w4));
       C.Ip = Ip;
-      const int gcol0 = cmin - A.half;  // image column of table column q = 0
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
         [[maybe_unused]] const unsigned long long rt0 = ROWTIME_NOW();
@@ -740,39 +942,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
             adr_t = at;
           }
         }
-        // ---- wgts[c][j]: lane = window column j, one centre per trip (its colour is one broadcast read)
-        if (wtab) {
-          for (int j0 = 0; j0 < A.n; j0 += kWave) {
-            const int j = j0 + lane;
-            const bool jon = j < A.n;
-            const int js = jon ? j : 0;
-            int adr_p = strip_a + off_p + js * 4, adr_o = strip_a + off_w + js * 8;
-            int col = gcol0 + js;
-            constexpr int U = 4;
-            for (int c0 = 0; c0 < ncent; c0 += U) {
-              uint32_t ic[U], pq[U];
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                ic[u] = lds_ld<uint32_t>(ipc_a + (c0 + u) * 4);  // c0 + u < ncent + U: inside the wave's LDS, the value is not used beyond ncent
-                pq[u] = lds_ld<uint32_t>(adr_p + u * 4);
-              }
-              double w[U];
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                int sad = (int)__builtin_amdgcn_sad_u8(ic[u], pq[u], 0u);
-                sad = ((unsigned)(col + u) < (unsigned)A.W) ? sad : kLutZero;  // outside the image: weight 0, the tap adds +0.0
-                w[u] = lut.w[sad];
-              }
-              int ao = adr_o;
-#pragma unroll
-              for (int u = 0; u < U; ++u) {
-                if (jon && c0 + u < ncent) *(__attribute__((address_space(3))) double *)(uintptr_t)(unsigned)ao = w[u];
-                ao += A.n * 8;
-              }
-              adr_p += U * 4; adr_o = ao; col += U;
-            }
-          }
-        }
+        if (wtab) build_wtab(strip_a + off_p, ipc_a, strip_a + off_w);
         const double rowterm = b * (double)qy + c;  // q_disp_y, :155
         double Rsum;
         dma_wait();  // the strip reads above have returned (and the table writes are queued behind them): the strips may go

@@ -104,6 +104,14 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * CSPM_OPT_SWEEP_PAIRS_ACTIVE (read only): 1 when the current cost object carries the pairs. */
 #define CSPM_OPT_SWEEP_PAIRS 5
 #define CSPM_OPT_SWEEP_PAIRS_ACTIVE 6
+/* CSPM_OPT_TABLE_VOLUMES (set before cspm_build_cost_grd; GRD with fused cells only; default 1): when they fit the context's budget
+ * (48 GiB -- the device has 288 GB; a KITTI-size pair needs 1.2 GB, a 3000x2000 D=256 pair 30 GB) the cost constructor also keeps the GRD
+ * cells as d-major f64 volumes -- what PreCSPC keeps (pre_cs_pc.cc:50-73) -- and the row kernels (InitRandomPlane, ViewPropagation,
+ * PlaneRefinement) fill their per-row cell tables from them by LDS-DMA instead of recomputing the cells, wherever a wave's lanes
+ * agree on a narrow disparity range; everything else still computes cells on the fly.  Same cells: identical planes.  0 = never.
+ * CSPM_OPT_TABLE_VOLUMES_ACTIVE (read only): 1 when the current cost object carries them. */
+#define CSPM_OPT_TABLE_VOLUMES 7
+#define CSPM_OPT_TABLE_VOLUMES_ACTIVE 8
 int cspm_get_option(cspm_ctx *ctx, int key, long long *value);
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on

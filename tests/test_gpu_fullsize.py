@@ -240,6 +240,22 @@ def test_north_star_bar_c3_crop_reference_order(gpu_ctx, c3):
         assert within >= 0.995, (v, within, float(d.max()))
 
 
+def test_c3_computed_tables_equal_dma_filled_tables(gpu_ctx, c3):
+    """The row kernels' cell tables come from the device-cell volumes by LDS-DMA (the default when the volumes fit) or are computed
+    in LDS (pairs too large for the volumes, CSPM_OPT_TABLE_VOLUMES = 0): the same cells either way -- at the headline size, over
+    three iterations, every plane and cost identical."""
+    cfg, l, r, _, _ = c3
+    out = []
+    for tv in (True, False):
+        gpu_ctx.set_images(l, r)
+        gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"], table_volumes=tv)
+        gpu_ctx.patchmatch(3, seed=4711, schedule=0)
+        out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+    for v in (0, 1):
+        np.testing.assert_array_equal(out[0][v][0], out[1][v][0])
+        np.testing.assert_array_equal(out[0][v][1], out[1][v][1])
+
+
 def test_c3_persistent_sweep_vs_per_diagonal_launches(gpu_ctx, c3):
     """Full-size stress of the inter-workgroup hand-off (per-pixel done flags, agent-scope atomics across the 8 XCDs):
     the persistent sweep must give, repeatedly, exactly the plane field of the one-launch-per-diagonal sweep, whose

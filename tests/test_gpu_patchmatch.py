@@ -11,15 +11,19 @@ pytestmark = pytest.mark.gpu
 MODES = [("ss", 0, 0.0), ("cs", 5, 0.3)]
 
 
-def _setup(ctx, pair, scale_num, lam, volumes=False, sweep_pairs=False):
-    """volumes: False = fused cells everywhere (the default build), "pairs" = fused cells + paired-cell volumes for the raster
-    sweep (CSPM_OPT_SWEEP_PAIRS), True = materialised f64 volumes"""
+def _setup(ctx, pair, scale_num, lam, volumes=False, sweep_pairs=False, table_volumes=True):
+    """volumes: False = fused cells + the device-cell volumes the row kernels' tables are DMA-filled from (the default build),
+    "computed" = fused cells, tables computed (CSPM_OPT_TABLE_VOLUMES = 0: what a pair too large for the volumes gets), "pairs" =
+    the default + paired-cell volumes for the raster sweep (CSPM_OPT_SWEEP_PAIRS), True = materialised f64 volumes read directly"""
     if volumes == "pairs":
         volumes, sweep_pairs = False, True
+    if volumes == "computed":
+        volumes, table_volumes = False, False
     ctx.set_images(pair["l"], pair["r"])
-    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam, volumes=volumes, sweep_pairs=sweep_pairs)
+    ctx.build_cost_grd(pair["max_dis"], 35, scale_num, lam, volumes=volumes, sweep_pairs=sweep_pairs, table_volumes=table_volumes)
     from crossscalepatchmatch_amd import capi
     assert ctx.get_option(capi.OPT_SWEEP_PAIRS_ACTIVE) == int(bool(sweep_pairs) and not volumes)
+    assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == int(bool(table_volumes) and not volumes)
     pc = po.PlaneCost(pair["l"], pair["r"], pair["max_dis"], 35, scale_num, lam)
     pm = po.PatchMatch(pair["l"], pair["r"], pair["max_dis"], 4)
     return pc, pm
@@ -34,7 +38,7 @@ def _assert_state_equal(ctx, pm, what):
         np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"{what}: min_cost, view {v}")
 
 
-@pytest.mark.parametrize("volumes", [False, "pairs", True], ids=["fused", "sweep_pairs", "volumes"])
+@pytest.mark.parametrize("volumes", [False, "computed", "pairs", True], ids=["fused", "computed_tables", "sweep_pairs", "volumes"])
 @pytest.mark.parametrize("name,scale_num,lam", MODES)
 @pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER])
 def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched, volumes):
@@ -54,13 +58,15 @@ def test_phase_by_phase(gpu_ctx, small_pair, name, scale_num, lam, sched, volume
 
 @pytest.mark.parametrize("pairname", ["mid_pair", "odd_pair"])
 @pytest.mark.parametrize("name,scale_num,lam", MODES)
-@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER, "raster_pairs"])
+@pytest.mark.parametrize("sched", [po.SCHED_REDBLACK, po.SCHED_RASTER, "raster_pairs", "raster_computed_tables"])
 def test_whole_pipeline_bit_exact(gpu_ctx, request, pairname, name, scale_num, lam, sched):
     """T3/T4: PatchMatch(3, plane_cost, false) + PlaneToDisp."""
     pair = request.getfixturevalue(pairname)
     src = False
     if sched == "raster_pairs":
         sched, src = po.SCHED_RASTER, "pairs"
+    if sched == "raster_computed_tables":
+        sched, src = po.SCHED_RASTER, "computed"
     pc, pm = _setup(gpu_ctx, pair, scale_num, lam, src)
     pm.run(3, pc, False, seed=4242, schedule=sched, sum_order=po.SUM_DEVICE, rb_rounds=1, rb_neighbours=4)
     gpu_ctx.patchmatch(3, seed=4242, schedule=sched, rb_rounds=1, rb_neighbours=4, early_exit=1)
