@@ -15,10 +15,12 @@
 //     the image border carry the per-tap column mask); rows on which every lane interpolates (nearly all once the planes have
 //     settled) run without clamp, validity test and select;
 //   * the running sums are registers of the lane: no cross-lane reduction, no per-level table set-up;
-//   * on the coarse pyramid levels, where the 64 lanes share a few centres and columns, the wave builds per-row tables of cells
-//     and guide weights once and the taps read those (cell mode).
-// Per tap and lane: 23.3 VALU instructions in an all-valid row, 27.4 in a general row, ~10 in cell mode, and 6.3 LDS reads
-// (DESIGN.md section 5.1), no global load.
+//   * where the 64 lanes of a wave agree on a few disparities -- the coarse pyramid levels always, the fine ones once the planes have
+//     settled -- the taps read per-row TABLES of cells (and, where they fit, of guide weights) instead: the cells of a window row
+//     that the wave can touch are a rectangle (columns x disparities) of the level's device-cell volume and move into LDS by DMA
+//     (Level::cvol), or are computed there once per row when the cost object carries no volume (cell mode below).
+// Per tap and lane: 23.3 VALU instructions in an all-valid row, 27.4 in a general row, 9.6 - 11.6 in a table row, and 6.3 / 3.6 LDS
+// reads, no global load.
 #pragma once
 #include "cspm_tap.h"
 
@@ -419,7 +421,8 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// CELL MODE (coarse pyramid levels of the fused GRD cost).  At level s the 64 lanes of a wave share 64 >> s distinct centres,
+// CELL MODE (fused GRD cost; full-range tables on the coarse pyramid levels, range-restricted ones wherever a wave's lanes agree on a few
+// disparities; level_rows decides per level pass).  At level s the 64 lanes of a wave share 64 >> s distinct centres,
 // the window row they walk has only (64 >> s) + 2*half distinct columns, and the level has few disparities: the wave touches
 // NQ x D distinct cells and ncent x n distinct guide weights on a window row, against 64 x n x 2 cell evaluations and 64 x n
 // weight look-ups when every lane works for itself.  So the wave first builds, per window row,
@@ -427,7 +430,8 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
 //   wgts[c][j]   = exp(-|I_centre(c) - I(c + j)| / 10), 0 for a column outside the image (the same table)
 // in LDS and then walks the window: a tap is its disparity, two 8-byte cell reads, one weight read, the interpolation and the
 // accumulation -- 8 VALU instructions and 6 LDS cycles instead of 23 and 21.  Same terms, same order: identical results.
-// Used where it fits the wave's LDS (levels 3 and 4 of a KITTI pyramid); measured in DESIGN.md section 7.
+// The cell table is DMA-filled from the device-cell volume when there is one (same bits: k_grd_volume wrote them with grd_cell()'s
+// arithmetic), else built as above; measured in DESIGN.md sections 5.1 and 7.
 // ------------------------------------------------------------------------------------------------
 struct CellRow {
   int adr_c;   // lane: LDS address of the table row of disparity 0 at the lane's window column 0 (a virtual row: f indexes it)
