@@ -1731,6 +1731,12 @@ int cspm_fpm_commit(cspm_ctx *c, const double *cost) {
 
 #ifdef CSPM_ROW_STATS
 // debug build only (tools/row_stats.py): the row-engine statistics of cspm_rows.h g_rowstat
+int cspm_debug_unionstat(unsigned long long *out64, int reset) {
+  static unsigned long long z[64];
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(cspm::g_unionstat), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_unionstat), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  return CSPM_OK;
+}
 int cspm_debug_rowtime(unsigned long long *out64, int reset) {
   static unsigned long long z[64];
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(cspm::g_rowtime), sizeof z) != hipSuccess) return CSPM_ERR_HIP;

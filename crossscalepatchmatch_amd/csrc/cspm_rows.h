@@ -79,6 +79,9 @@ __device__ unsigned long long g_rangestat[16 * 8 * 8];
 // wave cycles (s_memtime) by level: [level][0] rows of cell / range mode: total, [1] waiting for the row's strips, [2] table build,
 // [3] number of such rows; [4..7] the same for the DMA-staged general rows ([6] unused)
 __device__ unsigned long long g_rowtime[8 * 8];
+// level passes that fail the range test only by the SPAN of their disparities, by the size of the UNION of the lanes' intervals:
+// [level][0] <= 8, [1] <= 11, [2] <= 16, [3] <= 24, [4] more
+__device__ unsigned long long g_unionstat[8 * 8];
 #define ROWTIME_NOW() __builtin_readcyclecounter()
 #define ROWTIME_ADD(slot, v) do { rowtime_acc[(slot) & 3] += (unsigned long long)(v); rowtime_base = (slot) & 4; } while (0)
 #define ROWTIME_FLUSH() do { if (lane == 0 && rowtime_acc[3]) for (int k_ = 0; k_ < 4; ++k_) atomicAdd(&g_rowtime[s * 8 + rowtime_base + k_], rowtime_acc[k_]); } while (0)
@@ -733,6 +736,14 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         }
       }
 #ifdef CSPM_ROW_STATS
+      if (range_ok && !cells_on && D <= 128) {  // what would a table of the UNION of the lanes' disparity intervals need?
+        unsigned m[4] = {0u, 0u, 0u, 0u};
+        for (int d = fl_lane; d <= fh_lane; ++d) m[(d >> 5) & 3] |= 1u << (d & 31);
+        for (int off = 1; off < kWave; off <<= 1)
+          for (int k = 0; k < 4; ++k) m[k] |= (unsigned)__shfl_xor((int)m[k], off, kWave);
+        const int un = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+        if (lane == 0) atomicAdd(&g_unionstat[s * 8 + (un <= 8 ? 0 : un <= 11 ? 1 : un <= 16 ? 2 : un <= 24 ? 3 : 4)], 1ull);
+      }
       if (lane == 0) {
         unsigned long long *g = &g_rangestat[(ctx.stat_slot * 8 + s) * 8];
         if (cells_on && !allv_level) atomicAdd(&g[7], 1ull);

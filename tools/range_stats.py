@@ -42,3 +42,11 @@ for s in range(5):
         print(f"level {s}: table rows {g[3]:9d}: {g[0] / g[3]:7.1f} ticks per row, waiting for the strips {g[1] / g[3]:6.1f}, table build {g[2] / g[3]:6.1f}")
     if g[7]:
         print(f"level {s}: general DMA rows {g[7]:9d}: {g[4] / g[7]:7.1f} ticks per row, waiting for the strips {g[5] / g[7]:6.1f}")
+L.cspm_debug_unionstat.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+u = (C.c_ulonglong * 64)()
+L.cspm_debug_unionstat(u, 1)
+for s in range(5):
+    g = [u[s * 8 + k] for k in range(5)]
+    if sum(g):
+        print(f"level {s}: passes with too wide a SPAN of disparities {sum(g):8d}; their UNION of disparities: <= 8: {g[0] / sum(g):5.3f}  <= 11: {g[1] / sum(g):5.3f}  "
+              f"<= 16: {g[2] / sum(g):5.3f}  <= 24: {g[3] / sum(g):5.3f}  more: {g[4] / sum(g):5.3f}")
