@@ -57,6 +57,12 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_TABLE_DMA_SINGLE
 #define CSPM_TABLE_DMA_SINGLE 1   // ... also with ONE table buffer where two do not fit (0: compute the table then)
 #endif
+#ifndef CSPM_OWN_SINGLE
+#define CSPM_OWN_SINGLE 1  // own-view gradient reads of a tap batch as volatile single reads off one base (0: through laundered copies of the base)
+#endif
+#ifndef CSPM_CELL_PITCH_IMM
+#define CSPM_CELL_PITCH_IMM 1  // DMA-filled tables: the usual pitches as instruction immediates (cell_row_taps); 0: always CellRow::stride
+#endif
 #ifndef CSPM_CELL_PAD
 #define CSPM_CELL_PAD 1    // cell tables with a pitch of a multiple of 256 bytes when they fit (no bank conflicts between table rows)
 #endif
@@ -166,6 +172,9 @@ __device__ __forceinline__ T lds_ld(int adr) {
   else if constexpr (sizeof(T) == 8) return T{v[0], v[1]};
   else return v;
 }
+// The same as a volatile access: the compiler keeps it a single instruction (two 8-byte reads off one base would be merged into
+// ds_read2_b64, which runs at half the rate of two ds_read_b64) and still folds the constant part of the address into the offset field
+__device__ __forceinline__ double lds_ld_single(int adr) { return *(volatile __attribute__((address_space(3))) const double *)(uintptr_t)(unsigned)adr; }
 // `adr`: LDS address of the LOWER of the two slots a tap reads (left view, GRD / census: slot of x-f-1; otherwise the first cell)
 template <int SRC, int VIEW>
 __device__ __forceinline__ void rd_cells(int adr, uint4 &o0, uint4 &o1) {
@@ -204,7 +213,14 @@ __device__ __forceinline__ uint4 rd_own(int adr_g, int adr_p, int j) {
   } else {
     const uint32_t pix = lds_ld<uint32_t>(adr_p + j * 4);
     uint2 g{0u, 0u};
-    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) g = lds_ld<uint2>(adr_g + j * 8);
+    if constexpr (SRC == kSrcGrd || SRC == kSrcImg) {
+#if CSPM_OWN_SINGLE
+      const u32x2 v = *(volatile __attribute__((address_space(3))) const u32x2 *)(uintptr_t)(unsigned)(adr_g + j * 8);  // never ds_read2_b64 (lds_ld_single)
+      g = uint2{v[0], v[1]};
+#else
+      g = lds_ld<uint2>(adr_g + j * 8);
+#endif
+    }
     return uint4{g.x, g.y, pix, 0u};
   }
 }
@@ -305,10 +321,22 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
   uint4 P[N], o0[N], o1[N];
   double fr[N], wgt[N], tmp[N];
   bool valid[N], in_img[N];
-  // stage 1: own elements.  (The taps of a batch address the gradient array through separate, laundered copies of its base: two
-  // 8-byte reads off the same register would be merged into one ds_read2_b64, which runs at half the rate of ds_read_b64.)
+  // stage 1: own elements.  (Two 8-byte reads off the same register would be merged into one ds_read2_b64, which runs at half the
+  // rate of ds_read_b64: the gradient reads are volatile -- until round 4 they went through laundered copies of the base.)
+  if constexpr (STAGED && CSPM_OWN_SINGLE && (SRC == kSrcGrd || SRC == kSrcImg)) {
+    // colours first (they may pair up into ds_read2_b32, same rate), then the gradients as single 8-byte reads
 #pragma unroll
-  for (int k = 0; k < N; ++k) P[k] = STAGED ? rd_own<SRC>(k == 0 ? adr_g : k == 1 ? adr_g2 : adr_g3, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
+    for (int k = 0; k < N; ++k) P[k].z = lds_ld<uint32_t>(adr_p + (J0 + k) * 4);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const u32x2 v = *(volatile __attribute__((address_space(3))) const u32x2 *)(uintptr_t)(unsigned)(adr_g + (J0 + k) * 8);  // never ds_read2_b64
+      P[k].x = v[0]; P[k].y = v[1]; P[k].w = 0u;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      P[k] = STAGED ? rd_own<SRC>(CSPM_OWN_SINGLE || k == 0 ? adr_g : k == 1 ? adr_g2 : adr_g3, adr_p, J0 + k) : ld_elem<SRC>(R.own_row, off_g + (J0 + k) * E);
+  }
   // stage 2: disparities (pure arithmetic), then the cells of the other view
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -440,13 +468,14 @@ struct CellRow {
   int adr_c;   // lane: LDS address of the table row of disparity 0 at the lane's window column 0 (a virtual row: f indexes it)
   int stride;  // bytes between consecutive disparities: NQ * 8
   int adr_w;   // lane: LDS address of wgts[centre of the lane][0]                                (WTAB)
-  int adr_w2, adr_w3, adr_w4;  // == adr_w, opaque to the compiler: the weight reads of a batch must not be merged into ds_read2_b64 (half rate)
   int adr_p;   // lane: LDS address of the own view's colour of the lane's window column 0        (!WTAB: guide weights on the fly)
   uint32_t Ip; // the centre's colour                                                             (!WTAB)
 };
 // WTAB: the guide weights come from the per-row table wgts[centre][column]; otherwise every tap forms its own (own colour from the
 // strip set, |dI| -> exp table: :161-164) -- levels with too many centres for the table, rows inside the image only
-template <bool ALLV, bool WTAB, int J0, int J1>
+// STRIDE > 0: the table's row pitch in bytes as a compile-time constant -- the second cell is then read off the first one's address with
+// an immediate displacement (one address computation per tap instead of two); 0: the pitch is CellRow::stride
+template <bool ALLV, bool WTAB, int J0, int J1, int STRIDE = 0>
 __device__ __forceinline__ void cell_batch(const RowLevel &A, const Luts &lut, const CellRow &C, int adr_c, int adr_c1, int adr_w, int adr_p, int g8,
                                            double pa, double Gg, double S[kRowMod]) {
   constexpr int N = J1 - J0;
@@ -464,12 +493,17 @@ __device__ __forceinline__ void cell_batch(const RowLevel &A, const Luts &lut, c
     const DispSplit d = ALLV ? split_disp_valid(q_disp) : split_disp(q_disp, A.Dm1, A.has_valid);
     fr[k] = d.fr;
     valid[k] = d.valid;
-    int a0, a1;
+    int a0;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a0) : "v"(d.f), "s"(C.stride), "v"(adr_c));
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(d.f), "s"(C.stride), "v"(adr_c1));
     c0[k] = lds_ld<double>(a0 + j * 8);
-    c1[k] = lds_ld<double>(a1 + j * 8);
-    if constexpr (WTAB) w[k] = lds_ld<double>((k == 0 ? adr_w : k == 1 ? C.adr_w2 : k == 2 ? C.adr_w3 : C.adr_w4) + g8 + j * 8);
+    if constexpr (STRIDE > 0) {
+      c1[k] = lds_ld_single(a0 + STRIDE + j * 8);
+    } else {
+      int a1;
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a1) : "v"(d.f), "s"(C.stride), "v"(adr_c1));
+      c1[k] = lds_ld<double>(a1 + j * 8);
+    }
+    if constexpr (WTAB) w[k] = lds_ld_single(adr_w + j * 8);  // single reads: merged into ds_read2_b64 they run at half rate
   }
   if constexpr (!WTAB) {
 #pragma unroll
@@ -483,17 +517,20 @@ __device__ __forceinline__ void cell_batch(const RowLevel &A, const Luts &lut, c
     S[J0 + k] = __builtin_fma(w[k], t, S[J0 + k]);
   }
 }
-template <bool ALLV, bool WTAB, int CNT>
+template <bool ALLV, bool WTAB, int CNT, int STRIDE = 0>
 __device__ __forceinline__ void cell_group(const RowLevel &A, const Luts &lut, const CellRow &C, int g0, double pa, double rowterm, double &qxg_d,
                                            double S[kRowMod]) {
   const double Gg = group_disp(pa, qxg_d, rowterm);
   qxg_d += (double)kRowMod;
-  const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w, adr_p = C.adr_p + g0 * 4;
+  const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w + g8, adr_p = C.adr_p + g0 * 4;
   constexpr int SUB = 4;
-  cell_batch<ALLV, WTAB, 0, (CNT < SUB ? CNT : SUB)>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
-  if constexpr (CNT > SUB) cell_batch<ALLV, WTAB, SUB, CNT>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
+  cell_batch<ALLV, WTAB, 0, (CNT < SUB ? CNT : SUB), STRIDE>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
+  if constexpr (CNT > SUB) cell_batch<ALLV, WTAB, SUB, CNT, STRIDE>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
 }
-template <bool ALLV, bool WTAB>
+// PITCH_IMM: the pitches level_rows chooses for a 35 x 35 window on 64-pixel segments (level 0 padded / unpadded, level 1 padded /
+// unpadded, levels 2, 3, 4) run the groups of seven with the pitch as an immediate; anything else (other window sizes, ragged
+// segments, computed tables) with CellRow::stride.
+template <bool ALLV, bool WTAB, bool PITCH_IMM = false>
 __device__ __forceinline__ double cell_row_taps(const RowLevel &A, const Luts &lut, const CellRow &C, double pa, double rowterm, double qx0_d) {
   double S[kRowMod];
 #pragma unroll
@@ -501,7 +538,18 @@ __device__ __forceinline__ double cell_row_taps(const RowLevel &A, const Luts &l
   double qx_d = qx0_d;
   const int full = A.n / kRowMod * kRowMod;
   int g0 = 0;
-  for (; g0 < full; g0 += kRowMod) cell_group<ALLV, WTAB, kRowMod>(A, lut, C, g0, pa, rowterm, qx_d, S);
+  bool done = false;
+  if constexpr (PITCH_IMM && CSPM_CELL_PITCH_IMM) {
+    done = true;
+    switch (C.stride) {
+#define CSPM_PITCH(P) case P * 8: for (; g0 < full; g0 += kRowMod) cell_group<ALLV, WTAB, kRowMod, P * 8>(A, lut, C, g0, pa, rowterm, qx_d, S); break;
+      CSPM_PITCH(128) CSPM_PITCH(100) CSPM_PITCH(80) CSPM_PITCH(68) CSPM_PITCH(52) CSPM_PITCH(44) CSPM_PITCH(40)
+#undef CSPM_PITCH
+      default: done = false; break;
+    }
+  }
+  if (!done)
+    for (; g0 < full; g0 += kRowMod) cell_group<ALLV, WTAB, kRowMod>(A, lut, C, g0, pa, rowterm, qx_d, S);
   switch (A.n - full) {
 #define CSPM_TAIL(K) case K: cell_group<ALLV, WTAB, K>(A, lut, C, g0, pa, rowterm, qx_d, S); break;
     CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
@@ -671,7 +719,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       if (have_cvol) {
         // two tables (the DMA of row dy+1 lands while the taps of row dy read theirs), two runs of own colours, the weight table
         // where it fits; table rows of an even number of entries (16-byte pieces).  At most 8 DMA instructions per table.
-        const int NQE = (NQ + 1) & ~1, NQD = NQP > NQE ? NQP : NQE;
+        const int NQE = (NQ + 3) & ~3, NQD = NQP > NQE ? NQP : NQE;  // multiples of 4 entries: 16-byte pieces, and the pitches cell_row_taps knows as immediates
         auto fits = [&](int nb, int n_, int pit, bool wt) { return nb * n_ * pit * 8 + 2 * p2 + (wt ? wtab_bytes : 0) <= lds_room && n_ * (pit / 2) <= 12 * kWave; };
         // in order of preference: two tables before one (with one, the fetch of the next row's table waits for this row's taps: its
         // latency is hidden by the other waves of the SIMD only), padded pitch before unpadded, the weight table before per-tap weights
@@ -827,10 +875,6 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       CellRow C;
       C.stride = pitch * 8;
       C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
-      C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
-      asm volatile("" : "+v"(C.adr_w2));
-      asm volatile("" : "+v"(C.adr_w3));
-      asm volatile("" : "+v"(C.adr_w4));
       C.Ip = Ip;
       // table row k holds disparity d_base + k (cluster B: b_lo + k - nd_a): f indexes row f - d_base (f - b_lo + nd_a)
       const int adr_c0 = strip_a + (cx - cmin) * 8 - (lane_b ? b_lo - nd_a : d_base) * C.stride;
@@ -859,9 +903,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
             const bool safe = (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
             allv = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
           }
-          Rsum = allv ? cell_row_taps<true, true>(A, lut, C, a, rowterm, qx0_d) : cell_row_taps<false, true>(A, lut, C, a, rowterm, qx0_d);
+          Rsum = allv ? cell_row_taps<true, true, true>(A, lut, C, a, rowterm, qx0_d) : cell_row_taps<false, true, true>(A, lut, C, a, rowterm, qx0_d);
         } else {
-          Rsum = cell_row_taps<true, false>(A, lut, C, a, rowterm, qx0_d);
+          Rsum = cell_row_taps<true, false, true>(A, lut, C, a, rowterm, qx0_d);
         }
         tree.push(dy, Rsum);
 #ifdef CSPM_ROW_STATS
@@ -917,10 +961,6 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
       C.stride = pitch * 8;
       C.adr_c = strip_a + off_c + (cx - cmin) * 8 - d_base * C.stride;  // table row k holds disparity d_base + k: f indexes row f - d_base
       C.adr_w = strip_a + off_w + (cx - cmin) * A.n * 8;
-      C.adr_w2 = C.adr_w3 = C.adr_w4 = C.adr_w;
-      asm volatile("" : "+v"(C.adr_w2));
-      asm volatile("" : "+v"(C.adr_w3));
-      asm volatile("" : "+v"(C.adr_w4));
       C.Ip = Ip;
       for (int dy = dy_lo; dy <= dy_hi; ++dy) {
         const int qy = cy - A.half + dy;
