@@ -57,6 +57,15 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_TABLE_DMA_SINGLE
 #define CSPM_TABLE_DMA_SINGLE 1   // ... also with ONE table buffer where two do not fit (0: compute the table then)
 #endif
+#ifndef CSPM_PREFER_WTAB
+#define CSPM_PREFER_WTAB 0   // DMA-filled range tables: 1 = the per-row guide-weight table wherever it fits; 0 = per-tap weights for waves of <= CSPM_WTAB_MAXC centres whose window is inside the image (building the table costs more than it saves once the cells are not computed: measured)
+#endif
+#ifndef CSPM_WTAB_MAXC
+#define CSPM_WTAB_MAXC 64
+#endif
+#ifndef CSPM_CELL_SUB
+#define CSPM_CELL_SUB 4  // table rows: taps of a group of seven whose LDS round trips are overlapped (4 + 3)
+#endif
 #ifndef CSPM_OWN_SINGLE
 #define CSPM_OWN_SINGLE 1  // own-view gradient reads of a tap batch as volatile single reads off one base (0: through laundered copies of the base)
 #endif
@@ -523,7 +532,7 @@ __device__ __forceinline__ void cell_group(const RowLevel &A, const Luts &lut, c
   const double Gg = group_disp(pa, qxg_d, rowterm);
   qxg_d += (double)kRowMod;
   const int g8 = g0 * 8, adr_c = C.adr_c + g8, adr_c1 = C.adr_c + C.stride + g8, adr_w = C.adr_w + g8, adr_p = C.adr_p + g0 * 4;
-  constexpr int SUB = 4;
+  constexpr int SUB = CSPM_CELL_SUB;
   cell_batch<ALLV, WTAB, 0, (CNT < SUB ? CNT : SUB), STRIDE>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
   if constexpr (CNT > SUB) cell_batch<ALLV, WTAB, SUB, CNT, STRIDE>(A, lut, C, adr_c, adr_c1, adr_w, adr_p, g8, pa, Gg, S);
 }
@@ -725,7 +734,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         // latency is hidden by the other waves of the SIMD only), padded pitch before unpadded, the weight table before per-tap weights
         for (int nb = 2; nb >= 1 && !tdma; --nb) {
           if (range_ok) {
-            if (CSPM_CELL_PAD && fits(nb, nd, NQD, true)) { tdma = true; pitch = NQD; }
+            if (!CSPM_PREFER_WTAB && CSPM_CELL_PAD && !edge && ncent <= CSPM_WTAB_MAXC && fits(nb, nd, NQD, false)) { tdma = true; pitch = NQD; wtab = false; }
+            else if (!CSPM_PREFER_WTAB && !edge && ncent <= CSPM_WTAB_MAXC && fits(nb, nd, NQE, false)) { tdma = true; pitch = NQE; wtab = false; }
+            else if (CSPM_CELL_PAD && fits(nb, nd, NQD, true)) { tdma = true; pitch = NQD; }
             else if (CSPM_CELL_PAD && !edge && fits(nb, nd, NQD, false)) { tdma = true; pitch = NQD; wtab = false; }
             else if (fits(nb, nd, NQE, true)) { tdma = true; pitch = NQE; }
             else if (!edge && fits(nb, nd, NQE, false)) { tdma = true; pitch = NQE; wtab = false; }
