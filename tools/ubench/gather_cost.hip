@@ -37,6 +37,51 @@ __global__ __launch_bounds__(320) void k_gather(const char *base, int pitch_elem
   if (acc == 0x12345678u) out[threadIdx.x] = acc;
 }
 
+// The same bytes by LDS-DMA: 9 window rows x 30 contiguous 16-byte pieces (480 B per row) per pass = 270 pieces = 5 instructions of
+// 64 lanes (the last one 14 lanes), 4 passes per item -- what staging a pass's rows of ONE view through LDS would issue.
+__global__ __launch_bounds__(320) void k_dma(const char *base, int pitch_elems, int rows, int n, unsigned *out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + (unsigned)wave * 5120u;
+  int ox = (blockIdx.x * 37) % (pitch_elems - 64), oy = (blockIdx.x * 11 + wave * 3) % (rows - 48);
+  for (int it = 0; it < n; ++it) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int e = i * 64 + lane, r = e / 30, pc = e - r * 30;
+        const unsigned voff = (unsigned)(((size_t)(oy + p * 9 + (r < 9 ? r : 0)) * pitch_elems + ox) * 12 + pc * 16);
+        if (e < 270) {
+          unsigned keep;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)i * 1024u);
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    ox = (ox + 1) % (pitch_elems - 64);
+  }
+  if (n < 0) out[threadIdx.x] = smem[threadIdx.x];
+}
+static void run_dma(const char *d, int pitch, int rows, unsigned *dout, int wg_per_cu) {
+  const int ncu = 256, n = 400;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(k_dma, dim3(ncu * wg_per_cu), dim3(320), 5 * 5120, 0, d, pitch, rows, 20, dout);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL(k_dma, dim3(ncu * wg_per_cu), dim3(320), 5 * 5120, 0, d, pitch, rows, n, dout);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  const double per_cu = (double)wg_per_cu * 5 * n * 20;
+  const double ns = ms * 1e6 / per_cu;
+  printf("%-28s %d workgroups/CU: %7.2f ms, %6.1f ns = %6.1f cycles (2.4 GHz) per DMA instruction and CU, %5.1f B/cycle/CU\n", "LDS-DMA dwordx4, row runs", wg_per_cu, ms, ns,
+         ns * 2.4, 270.0 * 16 / 5 / (ns * 2.4));
+}
+
 template <int BYTES>
 static void run(const char *d, int pitch, int rows, unsigned *dout, int wg_per_cu, const char *name) {
   const int ncu = 256, n = 400;
@@ -68,6 +113,7 @@ int main() {
     run<8>(d, pitch, rows, dout, wg, "dwordx2 (8 B elements)");
     run<12>(d, pitch, rows, dout, wg, "dwordx3 (12 B elements)");
     run<16>(d, pitch, rows, dout, wg, "dwordx4 (16 B elements)");
+    run_dma(d, pitch, rows, dout, wg);
   }
   return 0;
 }
