@@ -42,8 +42,14 @@ class HipPairFn:
     for torch's current stream as it is now; so k_pack_bgr never reads a half-received input block.  The pair writes its maps
     straight into the caller's output views (`out=`); torch's current stream is NOT made to wait per pair (that would chain the
     pairs of different contexts one after the other): run_batch calls order_after_pairs() before it lets a collective overwrite
-    a receive buffer, and finalize() before it reads the maps.  The tensors a pair reads and writes are kept referenced until
-    finalize() (they are used on streams torch's allocator does not own)."""
+    a receive buffer, and finalize() before it reads the maps.
+
+    Lifetime of the tensors a pair reads and writes (they are used on streams torch's allocator does not own, and the library may
+    REWRITE a pair's maps inside a later synchronising call when its sweep timed out, include/cspm.h): each pair records an event on
+    its stream and is held per context; when a context takes its next pair, the library has dropped the earlier pairs' replay
+    requests, so those whose event has completed are released -- at most the pairs actually in flight stay pinned, however long
+    the loop runs (a 200-pair block held 800 tensors until round 4).  finalize() is REQUIRED before the maps are consumed and
+    before the last pairs' tensors are freed: it is the synchronising call that raises asynchronous errors and makes the maps final."""
     writes_out = True
 
     def __init__(self, device_index, in_flight=2):
@@ -57,7 +63,8 @@ class HipPairFn:
         self.streams = [torch.cuda.ExternalStream(c.stream_ptr(), device=self.device) for c in self.ctxs]
         self.calls = 0
         self.ctx = self.ctxs[0]
-        self._held = []  # tensors in use by pairs that have been enqueued but not yet synchronised
+        import collections
+        self._held = [collections.deque() for _ in self.ctxs]  # per context: (event, tensors) of pairs enqueued and possibly still running
 
     def __call__(self, l, r, p, out=None, after=None):
         import torch
@@ -83,12 +90,18 @@ class HipPairFn:
         if out is None:
             out = [torch.empty((h, w), dtype=torch.uint8, device=l.device) for _ in range(2)]
         assert all(o.is_contiguous() and o.device == self.device and o.dtype == torch.uint8 for o in out)
-        self._held.append((out[0], out[1], l, r))
         if int(p["use_pp"]):
             ctx.postprocess_device(int(p["dis_scale"]), out[0].data_ptr(), out[1].data_ptr())
         else:
             for v in (0, 1):
                 ctx.disparity_u8_device(v, int(p["dis_scale"]), out[v].data_ptr())
+        held = self._held[k]
+        while held and held[0][0].query():  # earlier pairs of this context: superseded (no replay) and finished
+            held.popleft()
+        done = torch.cuda.Event()
+        done.record(stream)
+        held.append((done, out[0], out[1], l, r))
+        self.max_held = max(getattr(self, "max_held", 0), sum(len(q) for q in self._held))
         return out[0], out[1]
 
     def order_after_pairs(self):
@@ -104,7 +117,8 @@ class HipPairFn:
             for c in self.ctxs:
                 c.synchronize()
         finally:
-            self._held.clear()
+            for q in self._held:
+                q.clear()
 
     def close(self):
         try:

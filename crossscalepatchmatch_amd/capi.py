@@ -22,6 +22,7 @@ OPT_SWEEP_PAIRS = 5          # paired-cell volumes for the raster sweep: 0 never
 OPT_SWEEP_PAIRS_ACTIVE = 6   # read only
 OPT_TABLE_VOLUMES = 7        # device-cell volumes for the row kernels' DMA-filled tables: 1 when they fit (default), 0 never
 OPT_TABLE_VOLUMES_ACTIVE = 8 # read only
+OPT_VOLUME_FALLBACKS = 9     # read only: hipMalloc failures of an optional volume this context survived
 
 # every symbol include/cspm.h declares
 SYMBOLS = [
@@ -196,16 +197,20 @@ class StereoContext:
         self._chk(self.L.cspm_get_option(self.p, key, C.byref(v)))
         return v.value
 
-    def build_cost_grd(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False, sweep_pairs=False, table_volumes=True):
+    def build_cost_grd(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False, sweep_pairs=None, table_volumes=None):
         """volumes=False: fused on-the-fly GRD cells (default); True: materialised f64 cost volumes.
-        sweep_pairs (CSPM_OPT_SWEEP_PAIRS): False = the library's default, the raster sweep recomputes its cells from image gathers
-        like every other kernel; True = paired-cell volumes for the sweep when they fit the context's budget (an option that
+        sweep_pairs (CSPM_OPT_SWEEP_PAIRS): None = leave the context's setting alone (the library's default, off, or what the
+        environment variable CSPM_SWEEP_PAIRS / an earlier set_option chose); False = the raster sweep recomputes its cells from image
+        gathers like every other kernel; True = paired-cell volumes for the sweep when they fit the context's budget (an option that
         measured no faster).
-        table_volumes (CSPM_OPT_TABLE_VOLUMES): True = the library's default, device-cell volumes (when they fit) from which the row
-        kernels fill their cell tables by LDS-DMA; False = the tables are computed."""
+        table_volumes (CSPM_OPT_TABLE_VOLUMES): None = leave the context's setting alone (default on; CSPM_TABLE_VOLUMES=0 turns it
+        off); True = device-cell volumes (when they fit) from which the row kernels fill their cell tables by LDS-DMA; False = the
+        tables are computed."""
         self.set_option(OPT_GRD_VOLUMES, int(volumes))
-        self.set_option(OPT_SWEEP_PAIRS, int(bool(sweep_pairs)))
-        self.set_option(OPT_TABLE_VOLUMES, int(bool(table_volumes)))
+        if sweep_pairs is not None:
+            self.set_option(OPT_SWEEP_PAIRS, int(bool(sweep_pairs)))
+        if table_volumes is not None:
+            self.set_option(OPT_TABLE_VOLUMES, int(bool(table_volumes)))
         self._chk(self.L.cspm_build_cost_grd(self.p, max_dis, wnd_size, scale_num, reg_lambda))
 
     def build_cost_cen(self, max_dis, wnd_size=35, scale_num=0, reg_lambda=0.0, volumes=False):

@@ -89,6 +89,9 @@ struct cspm_ctx {
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   long long opt_table_volumes = 1;          // CSPM_OPT_TABLE_VOLUMES: device-cell volumes for the row engine's DMA-filled tables, when they fit
   long long table_volumes_limit = 48LL << 30; // bytes of such volumes a context may hold (env CSPM_TABLE_VOLUMES_MAX_MB): 288 GB of HBM per GPU, a few contexts in flight
+  double volumes_mem_fraction = 0.5;        // of the memory hipMemGetInfo reports free when a cost object is allocated, the share the optional volumes (cvol, vol2) may take (env CSPM_VOLUMES_MEM_FRACTION)
+  long long optional_volume_fallbacks = 0;  // times a hipMalloc of an optional volume failed and the pair went on without (CSPM_OPT_VOLUME_FALLBACKS)
+  int fault_volume_alloc = 0;               // fault injection for the tests: the n-th optional-volume allocation of this context fails (env CSPM_FAULT_VOLUME_ALLOC)
   unsigned long long *d_maxkeys = nullptr;
   int row_claim = -1;  // row kernels: -1 = claimed column bands for launches of several rounds (default), 0 / 1 = never / always (env CSPM_ROW_CLAIM, tests)
   unsigned int *d_rowq = nullptr;  // row kernels: the eight claim counters of a launch that claims its items (cspm_rows.h row_item)
@@ -119,6 +122,12 @@ struct cspm_ctx {
   // yet: when that run is repeated after a timeout they are produced again from the repeated run's planes
   struct OutReq { int post, view, dis_scale; void *o0, *o1; };
   std::vector<OutReq> out_reqs;
+  // a later request for the same kind of map into the same buffer replaces the earlier one (the buffer ends up holding the later map)
+  void remember_output(const OutReq &q) {
+    for (auto it = out_reqs.begin(); it != out_reqs.end(); ++it)
+      if (it->post == q.post && it->o0 == q.o0 && it->o1 == q.o1 && (q.post || it->view == q.view)) { out_reqs.erase(it); break; }
+    out_reqs.push_back(q);
+  }
   // CSPatchMatch over a foreign IPlaneCost (cspm_fpm_*): candidate buffers and what the pending batch was
   FpmCand fpm{nullptr, nullptr, nullptr, nullptr};
   long long fpm_cap = 0;
@@ -386,6 +395,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   // paired-cell volumes for the raster sweep (kSrcVol2): only when every level's indices fit the sweep's 28-bit element offsets
   // and 24-bit slab size and the whole set stays under the context's budget (C3: 2.2 GB; C5 would need 56 GB and keeps the fused sweep)
   bool with_pairs = false;
+  long long pairs_bytes = 0, cvol_bytes = 0;
   if (want_pairs) {
     long long bytes = 0;
     bool fits = true;
@@ -397,6 +407,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
       bytes += 2 * slab * std::max(D, 2) * 16;
     }
     with_pairs = fits && bytes <= c->sweep_pairs_limit;
+    pairs_bytes = bytes;
   }
   // device-cell volumes for the row engine's DMA-filled tables: C3 1.2 GB, a 3000 x 2000 D = 256 pair 30 GB (each level's volume
   // must stay below 4 GiB per 16 disparities: the DMA's 32-bit offsets span the slabs of one table)
@@ -409,9 +420,10 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     for (int s = 0; s < (scale_num > 0 ? scale_num : 1); ++s) {
       if (s > 0) { H = (H + 1) / 2; W = (W + 1) / 2; D = D / 2; }
       bytes += 2LL * (D + 1) * H * (W + 2 * cvpad_all) * 8;
-      if ((long long)H * (W + 2 * cvpad_all) * 8 * std::min(D + 1, 64) >= (1LL << 32)) fits32 = false;  // a table's slabs within 32-bit offsets
+      if ((long long)H * (W + 2 * cvpad_all) * 8 * std::min(D + 1, 64) >= (1LL << 32)) fits32 = false;  // the usual tables of <= 64 slabs within 32-bit offsets (the device checks every table's real span: cspm_rows.h span32)
     }
     with_cvol = fits32 && bytes <= c->table_volumes_limit;
+    cvol_bytes = bytes;
   }
   CostKey key;
   key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
@@ -459,18 +471,6 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         L.cvol[v] = nullptr;
         L.cvpad = cvpad_all;
         L.cvW = W + 2 * cvpad_all;
-        if (with_cvol) {
-          double *cv;
-          const size_t ncv = (size_t)(D + 1) * H * L.cvW + 64;  // + slack: the last DMA piece of the last row may run 8 bytes over
-          if ((rc = dalloc(c, &cv, ncv, &c->cost_allocs))) return rc;
-          HIPCHK(c, hipMemsetAsync(cv, 0, ncv * sizeof(double), c->stream));  // the pad columns stay 0.0; the image columns are rewritten per pair
-          L.cvol[v] = cv;
-        }
-        if (with_pairs) {
-          double2 *v2;
-          if ((rc = dalloc(c, &v2, (size_t)std::max(D, 2) * px, &c->cost_allocs))) return rc;  // slabs 0 .. D-1; a level with D < 2 is only ever addressed (slab 1), never used
-          L.vol2[v] = v2;
-        }
         if (with_vol) {
           double *vol;
           if ((rc = dalloc(c, &vol, (size_t)(D + 2) * px, &c->cost_allocs))) return rc;  // D+1 slabs and one guard slab (clamped taps of a level with D < 2)
@@ -497,6 +497,48 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
           c->cen_gray[v][s] = gray;
           c->cen_code[v][s] = code;
           L.pc[v] = pc;
+        }
+      }
+    }
+    // The OPTIONAL volumes come last: device-cell volumes for the DMA-filled tables and paired-cell volumes for the sweep are accelerators,
+    // never a reason to fail a pair.  They are taken only from memory that is free NOW (at most `volumes_mem_fraction` of it: the
+    // plane field, the sweep granules and the other contexts of the process still have to fit), and a hipMalloc that fails all the
+    // same releases what this pass took and the pair runs with computed tables / the fused sweep -- the results are identical.
+    if (with_cvol || with_pairs) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const long long field_b = (long long)c->W * c->H * 2 * (14 + 3 + kGranPerPixel + 2) * 8;  // ensure_field's arrays, if not there yet
+        long long avail = (long long)((double)free_b * c->volumes_mem_fraction) - (c->field_alloc ? 0 : field_b);
+        if (with_cvol && cvol_bytes > avail) with_cvol = false;
+        if (with_cvol) avail -= cvol_bytes;
+        if (with_pairs && pairs_bytes > avail) with_pairs = false;
+      }
+    }
+    const size_t mandatory = c->cost_allocs.size();
+    auto drop_optional = [&]() {  // give back whatever this pass allocated and run without either kind of volume
+      for (size_t i = mandatory; i < c->cost_allocs.size(); ++i) (void)hipFree(c->cost_allocs[i]);
+      c->cost_allocs.resize(mandatory);
+      for (int s = 0; s < cd.levels; ++s)
+        for (int v = 0; v < 2; ++v) cd.lv[s].cvol[v] = nullptr, cd.lv[s].vol2[v] = nullptr;
+      (void)hipGetLastError();  // the out-of-memory error is handled: do not leave it as the runtime's sticky last error
+      c->err.clear();
+      c->optional_volume_fallbacks++;
+    };
+    for (int s = 0; s < cd.levels && (with_cvol || with_pairs); ++s) {
+      Level &L = cd.lv[s];
+      const size_t px = (size_t)L.W * L.H;
+      for (int v = 0; v < 2 && (with_cvol || with_pairs); ++v) {
+        if (with_cvol) {
+          double *cv;
+          const size_t ncv = (size_t)(L.D + 1) * L.H * L.cvW + 64;  // + slack: the last DMA piece of the last row may run 8 bytes over
+          if ((c->fault_volume_alloc > 0 && --c->fault_volume_alloc == 0) || dalloc(c, &cv, ncv, &c->cost_allocs) != CSPM_OK) { drop_optional(); with_cvol = with_pairs = false; break; }
+          HIPCHK(c, hipMemsetAsync(cv, 0, ncv * sizeof(double), c->stream));  // the pad columns stay 0.0; the image columns are rewritten per pair
+          L.cvol[v] = cv;
+        }
+        if (with_pairs) {
+          double2 *v2;  // slabs 0 .. D-1; a level with D < 2 is only ever addressed (slab 1), never used
+          if ((c->fault_volume_alloc > 0 && --c->fault_volume_alloc == 0) || dalloc(c, &v2, (size_t)std::max(L.D, 2) * px, &c->cost_allocs) != CSPM_OK) { drop_optional(); with_cvol = with_pairs = false; break; }
+          L.vol2[v] = v2;
         }
       }
     }
@@ -930,6 +972,8 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_SWEEP_PAIRS")) c->opt_sweep_pairs = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_TABLE_VOLUMES")) c->opt_table_volumes = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_TABLE_VOLUMES_MAX_MB")) c->table_volumes_limit = std::max(0LL, atoll(e)) << 20;
+  if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
+  if (const char *e = getenv("CSPM_FAULT_VOLUME_ALLOC")) c->fault_volume_alloc = atoi(e);
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -1062,6 +1106,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_TABLE_VOLUMES: *value = c->opt_table_volumes; return CSPM_OK;
     case CSPM_OPT_TABLE_VOLUMES_ACTIVE: *value = (c->cost_alloc && c->cost.lv[0].cvol[0]) ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
     default: return fail(c, CSPM_ERR_ARG, "unknown option");
   }
 }
@@ -1482,7 +1527,7 @@ int cspm_disparity_u8_device(cspm_ctx *c, int view, int dis_scale, void *d_out) 
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
   // asynchronous: when the run in front of it has an unchecked sweep, remember the request -- a repeated run (sweep timeout)
   // writes the map again from ITS planes, so the caller never reads a map of the aborted run after a successful check
-  if (c->sweep_pending) c->out_reqs.push_back(cspm_ctx::OutReq{0, view, dis_scale, d_out, nullptr});
+  if (c->sweep_pending) c->remember_output(cspm_ctx::OutReq{0, view, dis_scale, d_out, nullptr});
   return enqueue_disp_u8(c, view, dis_scale, d_out);
 }
 
@@ -1540,7 +1585,7 @@ int cspm_postprocess_device(cspm_ctx *c, int dis_scale, void *d_l_out, void *d_r
   if (dis_scale < 1 || !d_l_out || !d_r_out) return fail(c, CSPM_ERR_ARG, "bad dis_scale / outputs");
   DevGuard guard_(c->device);
   if (!guard_.ok) return fail(c, CSPM_ERR_HIP, "hipSetDevice failed");
-  if (c->sweep_pending) c->out_reqs.push_back(cspm_ctx::OutReq{1, 0, dis_scale, d_l_out, d_r_out});  // see cspm_disparity_u8_device
+  if (c->sweep_pending) c->remember_output(cspm_ctx::OutReq{1, 0, dis_scale, d_l_out, d_r_out});  // see cspm_disparity_u8_device
   return enqueue_postprocess_device(c, dis_scale, d_l_out, d_r_out);
 }
 

@@ -714,7 +714,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const double qmax = __builtin_fmax(__builtin_fmax(q00, q01), __builtin_fmax(q10, q11));
         const bool safe = (qmin >= 1.0 + 0x1p-20) & (qmax <= (double)D - 0x1p-20);  // false for NaN
         f_lo = fl_lane = safe ? (int)(qmin - 0x1p-20) : 1;
-        f_hi = fh_lane = safe ? (int)(qmax + 0x1p-20) + 1 : 1;
+        f_hi = fh_lane = safe ? min((int)(qmax + 0x1p-20) + 1, D) : 1;  // qmax == D - 2^-20 exactly would name slab D + 1: no tap reads beyond slab D
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
           f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
@@ -729,7 +729,10 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         // two tables (the DMA of row dy+1 lands while the taps of row dy read theirs), two runs of own colours, the weight table
         // where it fits; table rows of an even number of entries (16-byte pieces).  At most 8 DMA instructions per table.
         const int NQE = (NQ + 3) & ~3, NQD = NQP > NQE ? NQP : NQE;  // multiples of 4 entries: 16-byte pieces, and the pitches cell_row_taps knows as immediates
-        auto fits = [&](int nb, int n_, int pit, bool wt) { return nb * n_ * pit * 8 + 2 * p2 + (wt ? wtab_bytes : 0) <= lds_room && n_ * (pit / 2) <= 12 * kWave; };
+        // (a table's slabs are addressed by 32-bit DMA offsets from its first one: n_ slabs must span < 4 GiB -- the host only guarantees
+        // that for 64 slabs, and a small window's table may hold more)
+        auto span32 = [&](int n_) { return (unsigned long long)n_ * (unsigned long long)L.H * (unsigned long long)L.cvW * 8ull < (1ull << 32); };
+        auto fits = [&](int nb, int n_, int pit, bool wt) { return nb * n_ * pit * 8 + 2 * p2 + (wt ? wtab_bytes : 0) <= lds_room && n_ * (pit / 2) <= 12 * kWave && span32(n_); };
         // in order of preference: two tables before one (with one, the fetch of the next row's table waits for this row's taps: its
         // latency is hidden by the other waves of the SIMD only), padded pitch before unpadded, the weight table before per-tap weights
         for (int nb = 2; nb >= 1 && !tdma; --nb) {
@@ -766,7 +769,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
             a_hi = __builtin_amdgcn_readfirstlane(a_hi);
             bl = __builtin_amdgcn_readfirstlane(bl);
             const int na = a_hi - f_lo + 1, nb_ = f_hi - bl + 1, nt = na + nb_;
-            const bool span_ok = (unsigned long long)(f_hi - f_lo + 1) * (unsigned long long)L.H * (unsigned long long)L.cvW * 8ull < (1ull << 32);  // 32-bit DMA offsets
+            const bool span_ok = span32(f_hi - f_lo + 1);  // 32-bit DMA offsets: cluster B's rows are addressed from cluster A's first slab
             if (nt < nd && span_ok) {
               for (int nb = 2; nb >= 1 && !tdma; --nb) {
                 if (CSPM_CELL_PAD && fits(nb, nt, NQD, true)) { tdma = true; pitch = NQD; }

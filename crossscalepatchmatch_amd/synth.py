@@ -60,6 +60,64 @@ def make_pair(w, h, max_dis, regions=8, seed=0):
     return left_u8, right_u8, gt_l, gt_r
 
 
+# Pairs the noise textures of make_pair never produce: exact ties between candidate planes, cells that are exactly 0, cells that
+# all saturate, truncation thresholds hit exactly.  The reference's accept rules are strict `<` (cs_patchmatch.cc:182,192,201,209,
+# 270,335), so on such inputs the traversal ORDER decides -- which is what a parallel implementation can get wrong.
+ADVERSARIAL_KINDS = ("blocks", "saturated", "dup_rows", "periodic", "black", "white", "identical", "stripes", "half_flat")
+
+
+def _shift_right_view(left, d):
+    """right(x) = left(x + d) with the last column repeated (integer disparity d everywhere)"""
+    h, w = left.shape[:2]
+    xs = np.minimum(np.arange(w) + int(d), w - 1)
+    return np.ascontiguousarray(left[:, xs])
+
+
+def make_adversarial(kind, w, h, max_dis, seed=0):
+    """returns (left_bgr u8 [h,w,3], right_bgr u8): tie-heavy / saturated / degenerate stereo pairs, no ground truth.
+    blocks:     constant-colour rectangles (w/5 x h/4), right = left shifted by max_dis/3 -- every plane inside a block costs the same
+    saturated:  the same rectangles with channels drawn from {0, 255} only -- |colour difference| and gradient both truncate
+    dup_rows:   a noise texture whose rows 2k and 2k+1 are equal in both views -- the up and down neighbours tie
+    periodic:   a texture of horizontal period 6 (< max_dis): disparities d and d + 6 cost the same
+    black/white: constant 0 / 255 in both views -- every interior cell is exactly 0, min_cost == 0, no candidate is ever `<`
+    identical:  L == R (a noise texture): the true disparity 0 is the reference's "impossible" disparity (pre_cs_pc.cc:166)
+    stripes:    vertical 0/255 stripes 4 px wide, right shifted by 2: the gradient term saturates everywhere, colour ties
+    half_flat:  left half constant 128, right half noise -- flat and textured windows in one wavefront"""
+    rng = np.random.default_rng(seed)
+    if kind in ("blocks", "saturated"):
+        bw, bh = max(w // 5, 1), max(h // 4, 1)
+        ny, nx = -(-h // bh), -(-w // bw)
+        if kind == "blocks":
+            cols = rng.integers(0, 256, (ny, nx, 3))
+        else:
+            cols = rng.choice([0, 255], (ny, nx, 3))
+        left = np.repeat(np.repeat(cols, bh, 0), bw, 1)[:h, :w].astype(np.uint8)
+        return left, _shift_right_view(left, max(max_dis // 3, 1))
+    if kind == "dup_rows":
+        half = rng.integers(0, 256, (-(-h // 2), w, 3))
+        left = np.repeat(half, 2, 0)[:h].astype(np.uint8)
+        return left, _shift_right_view(left, max(max_dis // 4, 1))
+    if kind == "periodic":
+        tile = rng.integers(0, 256, (h, 6, 3))
+        left = np.tile(tile, (1, -(-w // 6), 1))[:, :w].astype(np.uint8)
+        return left, np.ascontiguousarray(np.roll(left, -2, axis=1))
+    if kind in ("black", "white"):
+        img = np.full((h, w, 3), 0 if kind == "black" else 255, np.uint8)
+        return img, img.copy()
+    if kind == "identical":
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        return img, img.copy()
+    if kind == "stripes":
+        col = (((np.arange(w) // 4) % 2) * 255).astype(np.uint8)
+        left = np.broadcast_to(col[None, :, None], (h, w, 3)).copy()
+        return left, _shift_right_view(left, 2)
+    if kind == "half_flat":
+        left = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        left[:, : w // 2] = 128
+        return left, _shift_right_view(left, max(max_dis // 2, 1))
+    raise ValueError(f"unknown adversarial kind {kind!r}; one of {ADVERSARIAL_KINDS}")
+
+
 def make_config(name, index=0):
     cfg = dict(CONFIGS[name])
     l, r, gl, gr = make_pair(cfg["w"], cfg["h"], cfg["max_dis"], cfg["regions"], cfg["seed"] + index)

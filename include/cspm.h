@@ -109,9 +109,15 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * cells as d-major f64 volumes -- what PreCSPC keeps (pre_cs_pc.cc:50-73) -- and the row kernels (InitRandomPlane, ViewPropagation,
  * PlaneRefinement) fill their per-row cell tables from them by LDS-DMA instead of recomputing the cells, wherever a wave's lanes
  * agree on a narrow disparity range; everything else still computes cells on the fly.  Same cells: identical planes.  0 = never.
- * CSPM_OPT_TABLE_VOLUMES_ACTIVE (read only): 1 when the current cost object carries them. */
+ * CSPM_OPT_TABLE_VOLUMES_ACTIVE (read only): 1 when the current cost object carries them.
+ * Both kinds of optional volume (this one and CSPM_OPT_SWEEP_PAIRS) are accelerators, never a reason for a pair to fail: beyond the
+ * per-context budgets they are taken only out of memory that hipMemGetInfo reports FREE when the cost object is allocated (at most
+ * half of it, env CSPM_VOLUMES_MEM_FRACTION), and when a hipMalloc for one of them fails all the same the constructor releases them
+ * and goes on with computed tables / the fused sweep -- identical results, as on a device with less HBM than MI355X's 288 GB.
+ * CSPM_OPT_VOLUME_FALLBACKS (read only): how many times such an allocation failed on this context. */
 #define CSPM_OPT_TABLE_VOLUMES 7
 #define CSPM_OPT_TABLE_VOLUMES_ACTIVE 8
+#define CSPM_OPT_VOLUME_FALLBACKS 9
 int cspm_get_option(cspm_ctx *ctx, int key, long long *value);
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on
@@ -175,7 +181,13 @@ int cspm_get_disparity_u8(cspm_ctx *ctx, int view, int dis_scale, uint8_t *out, 
 int cspm_get_disparity_f64(cspm_ctx *ctx, int view, double *out); /* unquantised a*x+b*y+c */
 /* device-resident result (u8, packed w*h) for the batch driver.  Asynchronous; when the PatchMatch run in front of it is repeated
  * after a sweep timeout (CSPM_OPT_SWEEP_TIMEOUT_MS), the map is written again from the repeated run's planes before the
- * synchronising call returns success. */
+ * synchronising call returns success.
+ * CONTRACT for every asynchronous output (this call and cspm_postprocess_device): the buffer must stay allocated, and its contents
+ * must not be consumed, until a synchronising cspm_* call on this ctx (cspm_synchronize, any cspm_get_*, cspm_postprocess) has
+ * returned CSPM_OK after the request.  Synchronising the stream or an event of your own is NOT enough: only the cspm_* call looks at
+ * the sweep's error word, and if the sweep timed out the map that stream-side synchronisation sees was written from the aborted run
+ * and is rewritten inside that cspm_* call.  Repeated requests for the same (buffer, kind) between two synchronising calls are
+ * recorded once. */
 int cspm_disparity_u8_device(cspm_ctx *ctx, int view, int dis_scale, void *d_out);
 /* PostProcessing (cs_patchmatch.cc:508-588) on the 8-bit maps */
 int cspm_postprocess(cspm_ctx *ctx, int dis_scale, uint8_t *l_out, uint8_t *r_out, size_t stride);

@@ -88,6 +88,74 @@ def test_scatter_compute_gather(world, n_pairs, chunk):
         np.testing.assert_array_equal(out[i, 1], dr.numpy())
 
 
+def _worker_c4(rank, world, port, n_pairs, ret, chunk):
+    """BASELINE configs[3] in shape: 200 pairs over 8 ranks.  Besides the maps, every rank reports which global indices (= seeds) it
+    computed and in which order, and how many scatter rounds it saw."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(15)
+    pairs = rng.integers(0, 256, (n_pairs, 2, 3, 5, 3)).astype(np.uint8) if rank == 0 else None
+    params = dict(w=5, h=3, max_dis=16, dis_scale=4, scale_num=5, reg_lambda=0.3, iters=3, seed=1000, schedule=0, use_pp=0) if rank == 0 else None
+    seeds = []
+
+    class Fn(_CountingFn):
+        def __call__(self, l, r, p):
+            seeds.append(int(p["seed"]))
+            return super().__call__(l, r, p)
+
+    fn = Fn()
+    scatters = []
+    real_scatter = dist.scatter
+
+    def counting_scatter(*a, **kw):
+        scatters.append(1)
+        return real_scatter(*a, **kw)
+
+    dist.scatter = counting_scatter
+    try:
+        out = batch.run_batch(pairs, params, fn, device="cpu", dist=dist, chunk_pairs=chunk)
+    finally:
+        dist.scatter = real_scatter
+    ret[f"seeds{rank}"] = seeds
+    ret[f"rounds{rank}"] = len(scatters)
+    assert fn.finalized == 1
+    if rank == 0:
+        ret["out"] = out.numpy()
+        ret["pairs"] = pairs
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pairs,chunk", [(8, 200, 4), (8, 5, 4)])
+def test_c4_shape_200_pairs_over_8_ranks(world, n_pairs, chunk):
+    """configs[3]: 200 pairs sharded over 8 ranks in rounds of 4 -- 25 pairs per rank = 7 scatter rounds with a ragged last one
+    (1 pair); and 5 pairs over 8 ranks (three ranks idle: they still take part in every collective).  Input order, seed = global
+    pair index, one finalize per rank, every rank sees the same number of rounds."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_c4, args=(world, _free_port(), n_pairs, ret, chunk), nprocs=world, join=True)
+    out, pairs = ret["out"], ret["pairs"]
+    assert out.shape == (n_pairs, 2, 3, 5)
+    sizes = batch.block_sizes(n_pairs, world)
+    cap = max(sizes)
+    rounds = -(-cap // min(chunk, cap))
+    for r in range(world):
+        a, b = batch.partition(n_pairs, world, r)
+        assert list(ret[f"seeds{r}"]) == [1000 + i for i in range(a, b)], f"rank {r}: seeds are global pair indices, in order"
+        assert ret[f"rounds{r}"] == rounds
+    if n_pairs == 200:
+        assert sizes == [25] * 8 and rounds == 7
+    p = dict(max_dis=16)
+    for i in range(n_pairs):
+        p["seed"] = 1000 + i
+        dl, dr = _fake_pair_fn(torch.from_numpy(pairs[i, 0]), torch.from_numpy(pairs[i, 1]), p)
+        np.testing.assert_array_equal(out[i, 0], dl.numpy())
+        np.testing.assert_array_equal(out[i, 1], dr.numpy())
+
+
 def test_single_process_path_and_no_cpu_fallback():
     rng = np.random.default_rng(6)
     pairs = rng.integers(0, 256, (3, 2, 4, 5, 3)).astype(np.uint8)

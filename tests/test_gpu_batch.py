@@ -95,3 +95,64 @@ def test_run_batch_over_rccl_world1(gpu_ctx, tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "batch_rank.py"), str(tmp_path)], check=True, env=env, timeout=600)
     got = np.load(tmp_path / "out.npy")
     np.testing.assert_array_equal(got, _direct(gpu_ctx, pairs))
+
+
+def test_run_batch_200_pairs_bounded_pinning(gpu_ctx):
+    """BASELINE configs[3] is a batch of 200 pairs: run_batch over 200 (small) pairs on one rank -- maps 0, 103 and 199 equal the
+    direct C-ABI path with seed = global pair index -- and HipPairFn pins only the pairs in flight, not the whole block
+    (round-4 review: `_held` grew to 200 x 4 tensors until finalize())."""
+    import torch
+    from crossscalepatchmatch_amd import batch
+    base = _pairs(8)
+    pairs = np.stack([base[i % 8] if (i // 8) % 2 == 0 else base[i % 8][:, :, ::-1].copy() for i in range(200)])  # 16 distinct inputs, 200 seeds
+    fn = batch.HipPairFn(0, in_flight=2)
+    got = batch.run_batch(pairs, dict(PARAMS), fn, device="cuda:0", dist=None)
+    torch.cuda.synchronize()
+    assert fn.calls == 200
+    assert fn.max_held <= 12, f"{fn.max_held} pairs pinned at once"  # the pairs in flight plus a few whose event had not been polled yet
+    assert sum(len(q) for q in fn._held) == 0  # finalize() released the rest
+    fn.close()
+    got = got.cpu().numpy()
+    assert got.shape == (200, 2, H, W)
+    for i in (0, 103, 199):
+        l, r = pairs[i]
+        gpu_ctx.set_images(l, r)
+        gpu_ctx.build_cost_grd(D, 35, PARAMS["scale_num"], PARAMS["reg_lambda"])
+        gpu_ctx.patchmatch(PARAMS["iters"], seed=PARAMS["seed"] + i, schedule=0)
+        for v in (0, 1):
+            np.testing.assert_array_equal(got[i, v], gpu_ctx.disparity_u8(v, 4), err_msg=f"pair {i} view {v}")
+
+
+def test_table_volumes_are_optional_memory(gpu_ctx, tmp_path):
+    """The device-cell volumes are an accelerator, not a requirement (advisor, round 4): a context whose share of the free memory
+    does not cover them, and one whose hipMalloc for them FAILS (fault injection), both go on with computed tables and produce
+    the same planes; the environment knob CSPM_TABLE_VOLUMES=0 is not overridden by the Python wrapper's defaults."""
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import capi
+    l, r = _pairs(1)[0]
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(D, 35, 5, 0.3)
+    assert gpu_ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 1
+    gpu_ctx.patchmatch(2, seed=4, schedule=0)
+    want = [gpu_ctx.get_planes(v) for v in (0, 1)]
+    for env, fallbacks in (({"CSPM_VOLUMES_MEM_FRACTION": "0"}, 0), ({"CSPM_FAULT_VOLUME_ALLOC": "3"}, 1), ({"CSPM_TABLE_VOLUMES": "0"}, 0)):
+        os.environ.update(env)
+        try:
+            ctx = cs.StereoContext(0)
+        finally:
+            for k in env:
+                del os.environ[k]
+        try:
+            ctx.set_images(l, r)
+            ctx.build_cost_grd(D, 35, 5, 0.3)
+            assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 0, env
+            assert ctx.get_option(capi.OPT_VOLUME_FALLBACKS) == fallbacks, env
+            ctx.patchmatch(2, seed=4, schedule=0)
+            for v in (0, 1):
+                npar, cost = ctx.get_planes(v)
+                np.testing.assert_array_equal(npar, want[v][0], err_msg=str(env))
+                np.testing.assert_array_equal(cost, want[v][1], err_msg=str(env))
+            ctx.build_cost_grd(D, 35, 5, 0.3)  # the next pair of the same shape reuses the buffers as they are: no retry, no error
+            assert ctx.get_option(capi.OPT_VOLUME_FALLBACKS) == fallbacks
+        finally:
+            ctx.close()
