@@ -118,18 +118,20 @@ def cpu_baseline_on(name, device_index=0, crop=None):
     }
 
 
-def cpu_baseline(device_index=0):
-    """The headline configuration first: C3 (configs[2], 1242x375, D=128, 5 levels) on a centred 320-column crop at full height and
-    full disparity range -- about a minute of host time in the reference's order (its raster sweep is serial); the whole pair would
-    take about four (the figure extrapolated by exact tap counts is given and labelled).  Then, as before, the whole of C2
-    (configs[1], 450x375, D=60, 5 levels: the reference's cross-scale path pre_cs_pc.cc:133-188) and the whole of C1 (configs[0],
-    single scale, the reference's own CPU-runnable case).  Every leg also runs the GPU on the same inputs: the north-star parity
-    figure (disparities within 0.5 px of the reference-order CPU result)."""
-    out = cpu_baseline_on("C3", device_index, crop=320)
+def cpu_baseline(device_index=0, crop=0, extra_legs=True):
+    """The headline configuration, WHOLE: C3 (configs[2], 1242x375, D=128, 5 levels) -- all 2 x 465 750 pixels in the reference's
+    order (its raster sweep is serial): three to four minutes on 16 host threads, no extrapolation (BASELINE.md section 4,
+    main.cc:92-126).  `crop` > 0 (flag --cpu-crop) times a centred column band of that width instead and labels the extrapolated
+    whole pair -- the bounded sample of earlier rounds, kept for quick runs.  Then, as before, the whole of C2 (configs[1], 450x375,
+    D=60, 5 levels: the reference's cross-scale path pre_cs_pc.cc:133-188) and the whole of C1 (configs[0], single scale, the
+    reference's own CPU-runnable case).  Every leg also runs the GPU on the same inputs: the north-star parity figure (disparities
+    within 0.5 px of the reference-order CPU result)."""
+    out = cpu_baseline_on("C3", device_index, crop=crop or None)
     out["sample"] += " (BASELINE.json configs[2], the configuration `value` is measured on)"
-    out["c2_cross_scale"] = cpu_baseline_on("C2", device_index)
-    out["c2_cross_scale"]["sample"] += " (BASELINE.json configs[1])"
-    out["c1_single_scale"] = cpu_baseline_on("C1", device_index)
+    if extra_legs:
+        out["c2_cross_scale"] = cpu_baseline_on("C2", device_index)
+        out["c2_cross_scale"]["sample"] += " (BASELINE.json configs[1])"
+        out["c1_single_scale"] = cpu_baseline_on("C1", device_index)
     return out
 
 
@@ -160,6 +162,9 @@ def main():
     ap.add_argument("--cc", default="GRD", choices=["GRD", "CEN", "IMG"],
                     help="cost function (BASELINE.json's metric is GRD; CEN = census; IMG = the volume-free GrdPC / CSPC plane costs, for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=0, help="CPU baseline on a centred crop of this many columns of C3 (with the whole pair extrapolated and "
+                                                            "labelled so) instead of the whole pair, which takes three to four minutes of host time")
+    ap.add_argument("--cpu-c3-only", action="store_true", help="CPU baseline: skip the C2 and C1 legs")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket launches with hipEvents")
     args = ap.parse_args()
 
@@ -373,7 +378,10 @@ def main():
                 "traffic": None,
                 "note": "bound = VALU issue: the tap stream never leaves the chip (see traffic vs algorithmic_bytes_per_launch), HBM at %.1f x its "
                         "peak by the algorithmic-byte yardstick.  frac = algorithmic f64 operations (14 per tap x in-image taps of one launch) / "
-                        "launch time / 3.93e13 lane-op/s (78.6 TFLOP/s f64 vector, an FMA counted once)." % (alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS),
+                        "launch time / 3.93e13 lane-op/s (78.6 TFLOP/s f64 vector, an FMA counted once).  frac is a yardstick of the REFERENCE's "
+                        "operation count, not a distance to an attainable 1.0: the kernel's table rows execute fewer VALU instructions per tap (8.1-10.3) "
+                        "than the 14 operations they are credited with, its general rows more (22-27); see valu_winstr_per_64_algorithmic_taps for "
+                        "what was actually issued." % (alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS),
             }
             # instruction-level view of the same launch from the committed rocprofv3 --pmc passes -- quoted only while the file
             # describes the kernels being timed (source hash) and the headline workload
@@ -436,7 +444,7 @@ def main():
         if nfl > 1:
             out["kernel_ms_one_pair_alone"] = {k: v["ms"] for k, v in solo.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
-            out["cpu_baseline"] = cpu_baseline(dev_index)
+            out["cpu_baseline"] = cpu_baseline(dev_index, crop=args.cpu_crop, extra_legs=not args.cpu_c3_only)
         # sanity of the LAST pair that was timed (not part of the timed region)
         if batch_mode:  # rank 0's last own pair: index steps-1 of the batch; its 8-bit map came back through the gather
             gl = host_pairs[min(args.steps, npairs) - 1][3]

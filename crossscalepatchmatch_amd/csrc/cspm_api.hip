@@ -42,10 +42,10 @@ struct DevGuard {
 
 // what the buffers of a cost object were sized for: an identical request reuses them (no hipMalloc / hipFree per pair)
 struct CostKey {
-  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1, with_pairs = 0, with_cvol = 0;
+  int W = 0, H = 0, max_dis = 0, wnd = 0, scale_num = -1, with_vol = 0, kind = -1, with_pairs = 0, with_cvol = 0, with_px8 = 0;
   bool operator==(const CostKey &o) const {
     return W == o.W && H == o.H && max_dis == o.max_dis && wnd == o.wnd && scale_num == o.scale_num && with_vol == o.with_vol && kind == o.kind &&
-           with_pairs == o.with_pairs && with_cvol == o.with_cvol;
+           with_pairs == o.with_pairs && with_cvol == o.with_cvol && with_px8 == o.with_px8;
   }
 };
 enum { kKindForeign = 0, kKindGrd = 1, kKindCen = 2, kKindImg = 3 };
@@ -89,6 +89,9 @@ struct cspm_ctx {
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   long long opt_table_volumes = 1;          // CSPM_OPT_TABLE_VOLUMES: device-cell volumes for the row engine's DMA-filled tables, when they fit
   long long table_volumes_limit = 48LL << 30; // bytes of such volumes a context may hold (env CSPM_TABLE_VOLUMES_MAX_MB): 288 GB of HBM per GPU, a few contexts in flight
+  long long opt_sweep_packed = 1;           // CSPM_OPT_SWEEP_PACKED: the raster sweep of a fused GRD cost reads packed 8-byte elements (kSrcGrd8); 0 = the 12-byte elements
+  bool sweep_packed = false;                // this cost object carries Level::px8
+  unsigned int *d_px8_bad = nullptr;        // device counter: gradients k_make_px8 could not pack (must stay 0)
   double volumes_mem_fraction = 0.5;        // of the memory hipMemGetInfo reports free when a cost object is allocated, the share the optional volumes (cvol, vol2) may take (env CSPM_VOLUMES_MEM_FRACTION)
   long long optional_volume_fallbacks = 0;  // times a hipMalloc of an optional volume failed and the pair went on without (CSPM_OPT_VOLUME_FALLBACKS)
   int fault_volume_alloc = 0;               // fault injection for the tests: the n-th optional-volume allocation of this context fails (env CSPM_FAULT_VOLUME_ALLOC)
@@ -429,6 +432,8 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   key.W = c->W; key.H = c->H; key.max_dis = max_dis; key.wnd = wnd_size; key.scale_num = scale_num; key.with_vol = with_vol; key.kind = kind;
   key.with_pairs = with_pairs;
   key.with_cvol = with_cvol;
+  const bool with_px8 = kind == kKindGrd && !with_vol && c->opt_sweep_packed != 0;
+  key.with_px8 = with_px8;
   const bool reuse = c->cost_alloc && key == c->cost_key;
   if (!reuse) free_cost(c);
   Cost &cd = c->cost;
@@ -463,6 +468,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         if ((rc = dalloc(c, &pxg, ppx, &c->cost_allocs))) return rc;
         L.px[v] = pxg;
         L.px16[v] = nullptr;
+        L.px8[v] = nullptr;
         L.pc[v] = nullptr;
         L.pix[v] = img;
         L.grd[v] = nullptr;
@@ -483,6 +489,11 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
           uint4 *p16;
           if ((rc = dalloc(c, &p16, ppx + 64, &c->cost_allocs))) return rc;
           L.px16[v] = p16;
+          if (with_px8) {
+            Pix8 *p8;
+            if ((rc = dalloc(c, &p8, ppx + 64, &c->cost_allocs))) return rc;  // + slack: a pair load at the last element reads one element beyond
+            L.px8[v] = p8;
+          }
         } else if (kind == kKindImg) {
           uint8_t *gray;
           if ((rc = dalloc(c, &gray, px, &c->cost_allocs))) return rc;
@@ -554,6 +565,8 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     c->d_lut_a = c->d_lut + kLutSize;
     if ((rc = dalloc(c, &c->d_maxcost, 2 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
     if ((rc = dalloc(c, &c->d_early_ok, 1, &c->cost_allocs))) return rc;
+    if ((rc = dalloc(c, &c->d_px8_bad, 1, &c->cost_allocs))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_px8_bad, 0, sizeof(unsigned int), c->stream));
     if ((rc = dalloc(c, &c->d_maxkeys, 4 * CSPM_MAX_LEVELS, &c->cost_allocs))) return rc;
     HIPCHK(c, hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     cd.lut = c->d_lut;
@@ -579,6 +592,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   c->is_cen = false;
   c->is_img = false;
   c->sweep_pairs = false;
+  c->sweep_packed = false;
   return CSPM_OK;
 }
 
@@ -755,6 +769,9 @@ inline void allow_lds(K kern, size_t shmem) {
     if (c->sweep_pairs && c->cost.fused == kSrcGrd) {                                                             \
       if (c->cost.cs) LAUNCH_ONE((kern<true, kSrcVol2>), grid, block, shmem, __VA_ARGS__);                        \
       else LAUNCH_ONE((kern<false, kSrcVol2>), grid, block, shmem, __VA_ARGS__);                                  \
+    } else if (c->sweep_packed && c->cost.fused == kSrcGrd) {                                                     \
+      if (c->cost.cs) LAUNCH_ONE((kern<true, kSrcGrd8>), grid, block, shmem, __VA_ARGS__);                        \
+      else LAUNCH_ONE((kern<false, kSrcGrd8>), grid, block, shmem, __VA_ARGS__);                                  \
     } else {                                                                                                      \
       LAUNCH_CS(kern, grid, block, shmem, __VA_ARGS__);                                                           \
     }                                                                                                             \
@@ -803,12 +820,13 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
 #ifdef CSPM_SWEEP_TRACE
     {
       static long long *d_trace = nullptr;
-      if (!d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * 8 * (size_t)sw.total);
+      if (!d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * kTraceSlots * (size_t)sw.total);
       sw.trace = d_trace;
       if (const char *path = getenv("CSPM_SWEEP_TRACE_FILE")) {
         static int sweep_no = 0;
-        if (sweep_no++ == 1) {  // dump the FIRST sweep's stamps when the second one is about to start
-          std::vector<long long> h((size_t)8 * sw.total);
+        const int dump_after = getenv("CSPM_SWEEP_TRACE_SWEEP") ? atoi(getenv("CSPM_SWEEP_TRACE_SWEEP")) : 1;  // dump sweep n when sweep n+1 is about to start
+        if (sweep_no++ == dump_after) {
+          std::vector<long long> h((size_t)kTraceSlots * sw.total);
           (void)hipStreamSynchronize(c->stream);
           (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
           if (FILE *fp = fopen(path, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), fp); fclose(fp); }
@@ -972,6 +990,7 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_SWEEP_PAIRS")) c->opt_sweep_pairs = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_TABLE_VOLUMES")) c->opt_table_volumes = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_TABLE_VOLUMES_MAX_MB")) c->table_volumes_limit = std::max(0LL, atoll(e)) << 20;
+  if (const char *e = getenv("CSPM_SWEEP_PACKED")) c->opt_sweep_packed = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
   if (const char *e = getenv("CSPM_FAULT_VOLUME_ALLOC")) c->fault_volume_alloc = atoi(e);
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
@@ -1087,6 +1106,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_RASTER_LAUNCHES: c->opt_raster_launches = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS: c->opt_sweep_pairs = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_TABLE_VOLUMES: c->opt_table_volumes = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PACKED: c->opt_sweep_packed = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -1107,6 +1127,17 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_TABLE_VOLUMES_ACTIVE: *value = (c->cost_alloc && c->cost.lv[0].cvol[0]) ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PACKED_ACTIVE: *value = c->sweep_packed ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_PACKED_BAD: {  // synchronises: gradients the packer could not represent (always 0 for 8-bit images)
+      if (!c->cost_alloc || !c->d_px8_bad) { *value = 0; return CSPM_OK; }
+      DevGuard guard_(c->device);
+      unsigned int bad = 0;
+      HIPCHK(c, hipMemcpyAsync(&bad, c->d_px8_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      *value = bad;
+      return CSPM_OK;
+    }
     default: return fail(c, CSPM_ERR_ARG, "unknown option");
   }
 }
@@ -1135,6 +1166,8 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
       // image v is the other view of view 1-v: the left view (0) reads the right image at x-f, x-f-1; the right view the left image at x+f, x+f+1
       hipLaunchKernelGGL(k_make_px16, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)g, L.Wp, L.H, v == 1 ? -1 : 1,
                          (uint4 *)L.px16[v]);
+      if (L.px8[v])
+        hipLaunchKernelGGL(k_make_px8, dim3(ew_grid(ppx)), dim3(256), 0, c->stream, L.pix[v], (const double *)g, ppx, (Pix8 *)L.px8[v], c->d_px8_bad);
     }
     const long long cells = (long long)L.W * L.H * (L.D + 1);
     for (int v = 0; v < 2; ++v) {
@@ -1147,6 +1180,7 @@ int cspm_build_cost_grd(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, d
   HIPCHK(c, hipGetLastError());
   cd.fused = with_vol ? kSrcVolume : kSrcGrd;
   c->sweep_pairs = cd.lv[0].vol2[0] != nullptr;
+  c->sweep_packed = !with_vol && cd.lv[0].px8[0] != nullptr;
   c->is_grd = true;
   return finish_cost(c, false);
 }

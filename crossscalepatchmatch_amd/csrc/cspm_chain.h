@@ -21,7 +21,7 @@ namespace cspm {
 
 // per-wave LDS scratch of the chain engine
 struct ChainScratch {
-  double part[kMaxPasses * kWave];    // chain sums of one candidate, pass-major
+  double part[2][kMaxPasses * kWave];  // chain sums of up to two candidates, pass-major
 };
 // Plane::param() of the candidates of one evaluation at one level
 struct ChainPlane { double a, b, c; };
@@ -68,6 +68,9 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
   } else if (SRC == kSrcCen) {
     A.px = reinterpret_cast<const char *>(L.pc[view]); A.opx = reinterpret_cast<const char *>(L.pc[1 - view]);
     A.Ip = L.pc[view][cy * L.Wp + L.pad + cx].pix;
+  } else if (SRC == kSrcGrd8) {
+    A.px = reinterpret_cast<const char *>(L.px8[view]); A.opx = reinterpret_cast<const char *>(L.px8[1 - view]);
+    A.Ip = pix8_colour(L.px8[view][cy * L.Wp + L.pad + cx].hi);
   } else {
     A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
     A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
@@ -79,21 +82,178 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
   return A;
 }
 
+#ifdef CSPM_SWEEP_TRACE
+constexpr int kTraceSlots = 16;
+__shared__ long long *s_tr;  // debug: the stamps of the item this workgroup works on (slots 0-7: wall clock per stage; 8-15: shader cycles inside one chain step)
+#define EVAL_STAMP(slot) do { if (wave == 0 && lane == 0 && s_tr) s_tr[slot] = wall_clock64(); } while (0)
+// s_memtime ordered after the values `dep...` are available (the compiler must have them in registers before the statement); volatile
+// asm statements keep their order.  lgkmcnt(0) also drains the wave's LDS reads: the stamps sit where the code waits for them anyway.
+__device__ __forceinline__ unsigned long long step_stamp(unsigned dep0, unsigned dep1) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep0), "v"(dep1) : "memory");
+  return t;
+}
+#else
+#define EVAL_STAMP(slot) do { } while (0)
+#endif
+#if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
+#define STEP_STAMP(k, d0, d1) do { if (trace_step) tstamp[k] = step_stamp((unsigned)(d0), (unsigned)(d1)); } while (0)
+#else
+#define STEP_STAMP(k, d0, d1) do { } while (0)
+#endif
+// Software pipelining of the chain steps (round 5): a step is a chain of dependent round trips -- gather (260-280 cycles even on an
+// empty GPU), exp-table LDS read (110), colour-table LDS read + cell arithmetic (170), ~200 cycles of address arithmetic and
+// bookkeeping (profiles/r05_sweep_step_budget.txt) -- and the raster sweep is 1 616 dependent pixel evaluations of 20 such steps
+// each.  The gathers of step st+1 (and of the next pass's first step) depend on nothing step st computes: they are issued BEFORE
+// step st is consumed, so their round trip hides behind its arithmetic.  Same operations, same order of every sum: identical bits.
+#ifndef CSPM_CHAIN_PIPE
+#define CSPM_CHAIN_PIPE 1
+#endif
+
 // One level, NC candidates (1 or 2) at the same pixel: the plane-independent half of every tap (own element, guide
 // weight) is computed once.  `pass_first/pass_step` let several waves share the passes of one level (single-scale sweep).
-// Chain sums are left in S[c][pass slot]; finish_level() turns them into the level sum.
+// The chain sums go straight into LDS: part[c][pass * 64 + lane] (round 5: no S[NC][passes] register array, a run-time pass loop --
+// the software-pipelined steps need the registers); finish_level() turns them into the level sum.
 template <int SRC, int NC>
 __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainPlane (&pl)[NC], int lane,
-                                             int pass_first, int pass_step, double S[NC][kMaxPasses]) {
+                                             int pass_first, int pass_step, double *const (&part)[NC]) {
   constexpr int E = SRC == kSrcVol2 ? 4 : elem_size<SRC>();
   const int lutzero = kLutZero;
   const int lr = lane / kRowMod, j = lane - lr * kRowMod;  // lane 63: lr = 9 -> never a valid chain
+#if CSPM_CHAIN_PIPE && !defined(CSPM_STEP_TRACE)
+  if constexpr (SRC == kSrcGrd || SRC == kSrcCen || SRC == kSrcGrd8) {
+    struct PassCtx {
+      bool chain_ok;
+      int ob;          // byte offset of the chain's first tap
+      double ty[NC];   // q_disp_y per candidate, :155
+    };
+    struct Fetched {   // everything step st needs from memory, and what its addresses were computed from
+      uint4 P;
+      uint4 o0[NC], o1[NC];  // kSrcGrd8: o0 = the pair {lower, upper address}; o1 unused
+      DispSplit d[NC];
+      bool ok;
+    };
+    const double jd = (double)j;
+    const int qx0 = A.ox0 + j;
+    auto make_ctx = [&](int p) {
+      PassCtx c;
+      const int r = p * kChainRows + lr;
+      c.chain_ok = (lr < kChainRows) & (r < A.nrows);
+      const int row = A.oy0 + A.r_lo + (c.chain_ok ? r : 0);  // image row; idle lanes shadow row r_lo with zero weight
+      c.ob = (row * A.Wp + A.pad + qx0) * E;
 #pragma unroll
-  for (int ps = 0; ps < kMaxPasses; ++ps) {
-    const int p = pass_first + ps * pass_step;
+      for (int k = 0; k < NC; ++k) c.ty[k] = pl[k].b * (double)row + pl[k].c;
+      return c;
+    };
+    auto fetch = [&](const PassCtx &c, int st, Fetched &F) {
+      const double xg = (double)(A.ox0 + kRowMod * st);  // q_x of the group's first column
+      const int dx = j + kRowMod * st;
+      F.ok = c.chain_ok & (dx < A.n) & ((unsigned)(qx0 + kRowMod * st) < (unsigned)A.W);
+      if constexpr (SRC == kSrcGrd8) {
+        const uint2 e = ld_pix8(A.px, c.ob + st * (kRowMod * E));
+        F.P = uint4{e.x, e.y, 0u, 0u};
+      } else {
+        F.P = ld_elem<SRC>(A.px, c.ob + st * (kRowMod * E));  // always inside the padded allocation
+      }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) S[c][ps] = 0.0;
-    if (p >= A.passes) continue;  // wave-uniform
+      for (int k = 0; k < NC; ++k) {
+        const double q_disp = tap_disp(pl[k].a, jd, group_disp(pl[k].a, xg, c.ty[k]));  // :165, device order
+        F.d[k] = split_disp(q_disp, A.Dm1, A.has_valid);
+        if constexpr (SRC == kSrcGrd8) {
+          F.o0[k] = ld_pix8_pair(A.opx, c.ob + st * (kRowMod * E) + __mul24(A.dirE, F.d[k].f) + (A.dirE < 0 ? -E : 0));
+        } else {
+          const int of = c.ob + st * (kRowMod * E) + __mul24(A.dirE, F.d[k].f);
+          F.o0[k] = ld_elem<SRC>(A.opx, of);
+          F.o1[k] = ld_elem<SRC>(A.opx, of + A.dirE);
+        }
+      }
+    };
+    auto consume = [&](const Fetched &F, double (&acc)[NC]) {
+      uint32_t Iq;
+      double XP = 0.0;
+      if constexpr (SRC == kSrcGrd8) { Iq = pix8_colour(F.P.y); XP = pix8_x(F.P.x, F.P.y); }
+      else Iq = pix_of<SRC>(F.P);
+      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, Iq, 0u);
+      const int sad = F.ok ? sad0 : lutzero;  // masked taps get weight entry kLutZero = 0.0: they add +0.0
+      const double wgt = lut.w[sad];          // :161-164
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        double c0, c1;
+        if constexpr (SRC == kSrcGrd8) {
+          const bool left = A.dirE < 0;  // the left view reads the right image at x-f and x-f-1: the pair is {f+1, f}
+          const uint4 pr = F.o0[k];
+          const double clo = grd8_cell(lut.a, Iq, XP, pix8_colour(pr.y), pix8_x(pr.x, pr.y));
+          const double chi = grd8_cell(lut.a, Iq, XP, pix8_colour(pr.w), pix8_x(pr.z, pr.w));
+          c0 = left ? chi : clo;
+          c1 = left ? clo : chi;
+        } else {
+          c0 = cell_of<SRC>(lut.a, F.P, F.o0[k]);
+          c1 = cell_of<SRC>(lut.a, F.P, F.o1[k]);
+        }
+        acc[k] = __builtin_fma(wgt, tap_value(F.d[k], c0, c1, A.maxc), acc[k]);  // :176-177
+      }
+    };
+    // field-wise copies: assigning the structs would also copy their padding bytes, which the compiler does through scratch memory
+    auto copy_fetched = [&](Fetched &d, const Fetched &f) {
+      d.P = f.P;
+      d.ok = f.ok;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) { d.o0[k] = f.o0[k]; d.o1[k] = f.o1[k]; d.d[k].valid = f.d[k].valid; d.d[k].f = f.d[k].f; d.d[k].fr = f.d[k].fr; }
+    };
+    auto copy_ctx = [&](PassCtx &d, const PassCtx &c) {
+      d.chain_ok = c.chain_ok;
+      d.ob = c.ob;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) d.ty[k] = c.ty[k];
+    };
+    if (pass_first >= A.passes) return;  // wave-uniform
+    PassCtx cur = make_ctx(pass_first);
+    Fetched F0, F1;
+    fetch(cur, 0, F0);
+    const int nsteps = A.nsteps;
+    for (int p = pass_first; p < A.passes; p += pass_step) {
+      const bool has_next = p + pass_step < A.passes;
+      PassCtx nxt;
+      if (has_next) nxt = make_ctx(p + pass_step);
+      else copy_ctx(nxt, cur);
+      double acc[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) acc[k] = 0.0;
+      // F0 holds step st.  Issue what comes after it -- step st+1, or the first step of this wave's next pass (of THIS pass again when
+      // there is none: a harmless reload) -- then consume it.  The fetches are unconditional: a fetch under a branch makes the
+      // compiler wait for ALL outstanding loads (vmcnt(0)) at the join, which undoes the pipelining.
+      int st = 0;
+      for (; st + 1 < nsteps; st += 2) {
+        fetch(cur, st + 1, F1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(F0, acc);
+        const bool in2 = st + 2 < nsteps;  // wave-uniform
+        PassCtx cb;
+        cb.chain_ok = in2 ? cur.chain_ok : nxt.chain_ok;
+        cb.ob = in2 ? cur.ob : nxt.ob;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) cb.ty[k] = in2 ? cur.ty[k] : nxt.ty[k];
+        fetch(cb, in2 ? st + 2 : 0, F0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(F1, acc);
+      }
+      if (st < nsteps) {  // an odd number of steps: F0 holds the last one; the next pass's first step goes to F1 and moves over
+        fetch(nxt, 0, F1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(F0, acc);
+        copy_fetched(F0, F1);
+      }
+#pragma unroll
+      for (int k = 0; k < NC; ++k) part[k][p * kWave + lane] = acc[k];
+      copy_ctx(cur, nxt);
+    }
+    return;
+  }
+#endif
+  for (int p = pass_first; p < A.passes; p += pass_step) {
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
     const int r = p * kChainRows + lr;
     const bool chain_ok = (lr < kChainRows) & (r < A.nrows);
     const int dy = A.r_lo + (chain_ok ? r : 0);  // window row; idle lanes shadow row r_lo with zero weight
@@ -104,15 +264,29 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
     for (int c = 0; c < NC; ++c) ty[c] = pl[c].b * (double)(A.oy0 + dy) + pl[c].c;  // q_disp_y, :155
     const double jd = (double)j;
     for (int st = 0; st < A.nsteps; ++st) {
+#if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
+      // one step of the item's first level-0 pass is stamped: wave 0 (level 0 / pass 0), its second pass, the middle step
+      const bool trace_step = (SRC == kSrcGrd || SRC == kSrcGrd8) && s_tr != nullptr && pass_first == 0 && A.n == cd.n && A.W == cd.lv[0].W && p == 1 && st == 2 &&
+                              __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+      unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      STEP_STAMP(0, st, p);
+#endif
       const double xg = (double)(A.ox0 + kRowMod * st);  // q_x of the group's first column
       const int dx = j + kRowMod * st;
       const bool ok = chain_ok & (dx < A.n) & ((unsigned)(qx0 + kRowMod * st) < (unsigned)A.W);
       uint4 P;
+      double XP = 0.0;  // kSrcGrd8: the own element's biased gradient
       if constexpr (SRC == kSrcVol2) P = uint4{0u, 0u, *reinterpret_cast<const uint32_t *>(A.px + (size_t)(unsigned)(ob + st * (kRowMod * E))), 0u};
-      else P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
-      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, SRC == kSrcVol2 ? P.z : pix_of<SRC>(P), 0u);
+      else if constexpr (SRC == kSrcGrd8) {
+        const uint2 e = ld_pix8(A.px, ob + st * (kRowMod * E));
+        P = uint4{0u, 0u, pix8_colour(e.y), 0u};
+        XP = pix8_x(e.x, e.y);
+      } else P = ld_elem<SRC>(A.px, ob + st * (kRowMod * E));  // always inside the padded allocation
+      const int sad0 = (int)__builtin_amdgcn_sad_u8(A.Ip, (SRC == kSrcVol2 || SRC == kSrcGrd8) ? P.z : pix_of<SRC>(P), 0u);
       const int sad = ok ? sad0 : lutzero;  // masked taps get weight entry kLutZero = 0.0: they add +0.0
+      STEP_STAMP(1, sad0, P.z);             // the own element has arrived
       const double wgt = lut.w[sad];        // :161-164
+      STEP_STAMP(2, __double2hiint(wgt), __double2loint(wgt));  // ... and the guide weight from the exp table
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const double q_disp = tap_disp(pl[c].a, jd, group_disp(pl[c].a, xg, ty[c]));  // :165, device order
@@ -122,7 +296,7 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           const int of = ((A.oy0 + dy) * A.Wp + A.pad + fxc) * E;
           const uint4 o0 = ld_elem<SRC>(A.opx, of), o1 = ld_elem<SRC>(A.opx, of + E);
           const double cell = img_cell(pix_of<SRC>(P), g_of(P), pix_of<SRC>(o0), g_of(o0), pix_of<SRC>(o1), g_of(o1), g.fw);
-          S[c][ps] = __builtin_fma(wgt, g.valid ? cell : A.maxc, S[c][ps]);
+          acc[c] = __builtin_fma(wgt, g.valid ? cell : A.maxc, acc[c]);
           continue;
         }
         const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
@@ -139,14 +313,44 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           const double *v = A.vol + (size_t)d.f * A.slab + (size_t)qy * A.W + qx;
           c0 = v[0];
           c1 = v[A.slab];
+        } else if constexpr (SRC == kSrcGrd8) {
+          // the two other-view elements of the tap (disparities f and f+1) are neighbours: ONE 16-byte gather from the lower address
+          const bool left = A.dirE < 0;  // the left view reads the right image at x-f and x-f-1
+          const int of = ob + st * (kRowMod * E) + __mul24(A.dirE, d.f) + (left ? -E : 0);
+          const uint4 pr = ld_pix8_pair(A.opx, of);
+          if (c == 0) STEP_STAMP(3, pr.x, pr.w);  // the other view's pair has arrived
+          const double clo = grd8_cell(lut.a, P.z, XP, pix8_colour(pr.y), pix8_x(pr.x, pr.y));
+          const double chi = grd8_cell(lut.a, P.z, XP, pix8_colour(pr.w), pix8_x(pr.z, pr.w));
+          c0 = left ? chi : clo;
+          c1 = left ? clo : chi;
+          if (c == 0) STEP_STAMP(4, __double2hiint(c0), __double2hiint(c1));  // both cells (colour table round trip included)
         } else {
           const int of = ob + st * (kRowMod * E) + __mul24(A.dirE, d.f);
+#if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
+          const uint4 o0 = ld_elem<SRC>(A.opx, of), o1 = ld_elem<SRC>(A.opx, of + A.dirE);
+          if (c == 0) STEP_STAMP(3, o0.x, o1.x);
+          c0 = cell_of<SRC>(lut.a, P, o0);
+          c1 = cell_of<SRC>(lut.a, P, o1);
+          if (c == 0) STEP_STAMP(4, __double2hiint(c0), __double2hiint(c1));
+#else
           c0 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of));
           c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of + A.dirE));
+#endif
         }
-        S[c][ps] = __builtin_fma(wgt, tap_value(d, c0, c1, A.maxc), S[c][ps]);  // :176-177
+        acc[c] = __builtin_fma(wgt, tap_value(d, c0, c1, A.maxc), acc[c]);  // :176-177
       }
+#if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
+      STEP_STAMP(5, __double2hiint(acc[0]), __double2hiint(acc[NC - 1]));  // the step's accumulations
+      if (trace_step) {
+        STEP_STAMP(6, 0, 0);
+        STEP_STAMP(7, 0, 0);  // two stamps back to back: what a stamp itself costs
+        if (lane == 0)
+          for (int k = 0; k < 8; ++k) s_tr[8 + k] = (long long)tstamp[k];
+      }
+#endif
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[c][p * kWave + lane] = acc[c];
   }
 }
 
@@ -165,17 +369,6 @@ __device__ __forceinline__ double finish_level(const ChainLevel &A, const double
   return wave_tree_sum(R);
 }
 
-// store the chain sums of candidate c (this wave's pass slots) into part[]
-template <int NC>
-__device__ __forceinline__ void store_parts(double *part, const double S[NC][kMaxPasses], int c, int lane, int pass_first, int pass_step,
-                                            int passes) {
-#pragma unroll
-  for (int ps = 0; ps < kMaxPasses; ++ps) {
-    const int p = pass_first + ps * pass_step;
-    if (p < passes) part[p * kWave + lane] = S[c][ps];
-  }
-}
-
 // Aggregated plane cost at (x,y) by ONE wave; +inf when the candidate is proven not to beat `thresh` (checked at
 // level ends with the exact partial total: all terms are >= 0 when Cost::early_ok).
 // (nx,ny,nz) = Plane::norm(), (pa,pb,pc) = Plane::param().
@@ -192,12 +385,11 @@ __device__ __forceinline__ double eval_plane_chain(const Cost &cd, const Luts &l
     if (CS) plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
     const ChainLevel A = make_chain_level<SRC>(cd, s, view, cur_x, cur_y);
     const ChainPlane pl[1] = {{a, b, c}};
-    double S[1][kMaxPasses];
-    chain_passes<SRC, 1>(cd, A, lut, pl, lane, 0, 1, S);
-    wave_lds_fence();  // earlier reads of part[] are done
-    store_parts<1>(m.part, S, 0, lane, 0, 1, A.passes);
+    double *const parts[1] = {m.part[0]};
+    wave_lds_fence();  // the previous level's reads of part[] are done
+    chain_passes<SRC, 1>(cd, A, lut, pl, lane, 0, 1, parts);
     wave_lds_fence();
-    const double sc = finish_level(A, m.part, lane);
+    const double sc = finish_level(A, m.part[0], lane);
     if (CS) cost += sc * cd.lv[s].wgt;  // :182
     else cost = sc;
     if (use_thresh && cost >= thresh) return __builtin_inf();
@@ -289,10 +481,10 @@ constexpr int kSweepMaxWaves = CSPM_MAX_LEVELS * kSweepWpl > kMaxPasses ? CSPM_M
 struct SweepShared {
   LutMem &lut;
   double (*lvl)[CSPM_MAX_LEVELS];  // [2][levels]: cross-scale, exact level sums
-  ChainScratch *m;                 // one per wave (at least two: the single-scale path gathers both candidates there)
+  ChainScratch *m;                 // one per wave (two candidates' chain sums each)
 };
 __host__ __device__ inline size_t sweep_shared_bytes(int waves) {
-  return sizeof(LutMem) + 2 * CSPM_MAX_LEVELS * sizeof(double) + (size_t)(waves < 2 ? 2 : waves) * sizeof(ChainScratch);
+  return sizeof(LutMem) + 2 * CSPM_MAX_LEVELS * sizeof(double) + (size_t)(waves < 1 ? 1 : waves) * sizeof(ChainScratch);
 }
 __device__ __forceinline__ SweepShared sweep_shared(unsigned char *smem) {
   return SweepShared{*reinterpret_cast<LutMem *>(smem), reinterpret_cast<double (*)[CSPM_MAX_LEVELS]>(smem + sizeof(LutMem)),
@@ -301,12 +493,6 @@ __device__ __forceinline__ SweepShared sweep_shared(unsigned char *smem) {
 
 // Both candidate costs at pixel (x,y) of view v; every wave of the workgroup calls it.  `both` = the two candidates differ
 // (otherwise only c0 is evaluated and cost1 = cost0).  Results are valid in wave 0 after the call.
-#ifdef CSPM_SWEEP_TRACE
-__shared__ long long *s_tr;  // debug: the 8 stamps of the item this workgroup works on
-#define EVAL_STAMP(slot) do { if (wave == 0 && lane == 0 && s_tr) s_tr[slot] = wall_clock64(); } while (0)
-#else
-#define EVAL_STAMP(slot) do { } while (0)
-#endif
 template <bool CS, int SRC>
 __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, const SweepShared &sh, int v, int x, int y, const Cand &c0,
                                                 const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
@@ -319,34 +505,26 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
     int cur_x = x, cur_y = y;
     for (int s = 0; s < level; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
     const ChainLevel A = make_chain_level<SRC>(cd, level < cd.levels ? level : 0, v, cur_x, cur_y);
-    double *part0 = sh.m[level * kSweepWpl].part, *part1 = sh.m[level * kSweepWpl + (kSweepWpl > 1 ? 1 : 0)].part;
+    double *part0 = sh.m[level * kSweepWpl].part[0], *part1 = sh.m[level * kSweepWpl].part[1];  // the level's first wave's scratch serves all its waves
     if (level < cd.levels) {
       ChainPlane pl[2];
       plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pl[0].a, pl[0].b, pl[0].c);  // :144-149
       if (both) {
         plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pl[1].a, pl[1].b, pl[1].c);
         EVAL_STAMP(4);
-        double S[2][kMaxPasses];
-        chain_passes<SRC, 2>(cd, A, lut, pl, lane, part_of, kSweepWpl, S);
+        double *const parts[2] = {part0, part1};
+        chain_passes<SRC, 2>(cd, A, lut, pl, lane, part_of, kSweepWpl, parts);
         EVAL_STAMP(5);
-        if (kSweepWpl > 1) {
-          store_parts<2>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
-          store_parts<2>(part1, S, 1, lane, part_of, kSweepWpl, A.passes);
-        } else {  // one wave per level: its own buffer serves both candidates in turn
-          store_parts<2>(part0, S, 0, lane, 0, 1, A.passes);
+        if (kSweepWpl == 1) {
           wave_lds_fence();
           const double s0 = finish_level(A, part0, lane);
-          wave_lds_fence();
-          store_parts<2>(part0, S, 1, lane, 0, 1, A.passes);
-          wave_lds_fence();
-          const double s1 = finish_level(A, part0, lane);
+          const double s1 = finish_level(A, part1, lane);
           if (lane == 0) { sh.lvl[0][level] = s0; sh.lvl[1][level] = s1; }
         }
       } else {
         const ChainPlane p1[1] = {pl[0]};
-        double S[1][kMaxPasses];
-        chain_passes<SRC, 1>(cd, A, lut, p1, lane, part_of, kSweepWpl, S);
-        store_parts<1>(part0, S, 0, lane, part_of, kSweepWpl, A.passes);
+        double *const parts[1] = {part0};
+        chain_passes<SRC, 1>(cd, A, lut, p1, lane, part_of, kSweepWpl, parts);
         if (kSweepWpl == 1) {
           wave_lds_fence();
           const double s0 = finish_level(A, part0, lane);
@@ -380,23 +558,19 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
     const int nw = (int)(blockDim.x >> 6);
     const ChainLevel A = make_chain_level<SRC>(cd, 0, v, x, y);
     const ChainPlane pl[2] = {{c0.a, c0.b, c0.c}, {c1.a, c1.b, c1.c}};
-    double S[2][kMaxPasses];
+    double *const parts[2] = {sh.m[0].part[0], sh.m[0].part[1]};  // the chain sums of all waves meet in wave 0's scratch
     if (both) {
-      chain_passes<SRC, 2>(cd, A, lut, pl, lane, wave, nw, S);
+      chain_passes<SRC, 2>(cd, A, lut, pl, lane, wave, nw, parts);
     } else {
       const ChainPlane p1[1] = {pl[0]};
-      double S1[1][kMaxPasses];
-      chain_passes<SRC, 1>(cd, A, lut, p1, lane, wave, nw, S1);
-#pragma unroll
-      for (int ps = 0; ps < kMaxPasses; ++ps) { S[0][ps] = S1[0][ps]; S[1][ps] = S1[0][ps]; }
+      double *const parts1[1] = {parts[0]};
+      chain_passes<SRC, 1>(cd, A, lut, p1, lane, wave, nw, parts1);
     }
-    store_parts<2>(sh.m[0].part, S, 0, lane, wave, nw, A.passes);
-    store_parts<2>(sh.m[1].part, S, 1, lane, wave, nw, A.passes);
     __syncthreads();
     cost0 = cost1 = 0.0;
     if (wave == 0) {
-      cost0 = finish_level(A, sh.m[0].part, lane);
-      cost1 = both ? finish_level(A, sh.m[1].part, lane) : cost0;
+      cost0 = finish_level(A, parts[0], lane);
+      cost1 = both ? finish_level(A, parts[1], lane) : cost0;
     }
   }
 }
@@ -478,7 +652,7 @@ struct Sweep {
   long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
 };
 #ifdef CSPM_SWEEP_TRACE
-#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[((size_t)2 * pm.W * by0 + item) * 8 + (slot)] = wall_clock64(); } while (0)
+#define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[((size_t)2 * pm.W * by0 + item) * kTraceSlots + (slot)] = wall_clock64(); } while (0)
 #else
 #define SWEEP_STAMP(slot) do { } while (0)
 #endif
@@ -544,7 +718,7 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
     if (item >= btotal) return;
     SWEEP_STAMP(0);
 #ifdef CSPM_SWEEP_TRACE
-    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + ((size_t)2 * pm.W * by0 + item) * 8 : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; } }
+    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + ((size_t)2 * pm.W * by0 + item) * kTraceSlots : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; for (int k = 8; k < kTraceSlots; ++k) s_tr[k] = 0; } }
 #endif
     while (k + 1 < ndiag && item >= bstart[k + 1]) ++k;  // items of one workgroup only increase
     const int ys_lo = max(by0, k - (pm.W - 1)), ys_hi = min(by1 - 1, k);

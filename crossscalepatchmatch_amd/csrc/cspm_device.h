@@ -52,6 +52,32 @@ enum { kSrcVol2 = 4 };  // raster sweep only (chain engine): GRD device cells ma
                         // the two cells a tap interpolates between (pre_cs_pc.cc:171-176) arrive with ONE 16-byte gather, the guide
                         // weight needs one 4-byte gather of the own colour: 2 gathers / 20 B per tap instead of 3 / 36 B
 
+enum { kSrcGrd8 = 5 };  // raster sweep only (chain engine), fused GRD: the same pixels as kSrcGrd in PACKED 8-byte elements (Pix8 below) -- a tap's
+                        // two adjacent other-view elements are 16 contiguous bytes = ONE dwordx4 gather, its own element one dwordx2 gather:
+                        // 2 gathers / 24 B per tap instead of 3 / 36 B through the CU's L1 return path, which is what bounds the sweep
+
+// The x-gradient of a GRD level (grd_cc.cpp:76-77) is gray[x+1] - gray[x-1] of the f32 gray image, and every f32 gray value of an
+// 8-bit colour is a multiple of 2^-27 below 256 (0.114f has ulp 2^-27; tests/test_oracle_primitives.py enumerates all 2^24 colours):
+// the gradient is an integer multiple of 2^-27 in (-256, 256) -- 36 bits.  With the 24 bits of colour that is a 60-bit pixel:
+//   lo  = low 32 bits of u,  u = g * 2^27 + 2^35  (36-bit unsigned)
+//   hi  = colour << 8 | u >> 32
+// Decoding is exact and nearly free: the double with the bits {(hi & 0xF) | 0x43300000, lo} is X = 2^52 + u, and a GRD cell only needs
+// |g_own - g_other| = |X_own - X_other| * 2^-27 (both exact), so the scale folds into the constants of the cell (grd8_cell, cspm_tap.h).
+struct __attribute__((aligned(8))) Pix8 {
+  uint32_t lo, hi;
+};
+static_assert(sizeof(Pix8) == 8, "Pix8 must be 8 bytes");
+constexpr double kPix8Scale = 134217728.0;      // 2^27
+constexpr double kPix8Bias = 34359738368.0;     // 2^35
+__host__ __device__ inline bool pix8_encode(uint32_t pix, double g, Pix8 *out) {
+  const double t = g * kPix8Scale + kPix8Bias;  // exact for every representable gradient
+  const bool ok = t >= 0.0 && t < 68719476736.0 && t == (double)(unsigned long long)t && (pix >> 24) == 0u;
+  const unsigned long long u = ok ? (unsigned long long)t : 0ull;
+  out->lo = (uint32_t)u;
+  out->hi = (pix << 8) | (uint32_t)(u >> 32);
+  return ok;
+}
+
 struct Level {
   int W, H, D;            // wid_[s], hei_[s], max_disp_[s]
   int Wp, pad;
@@ -59,6 +85,7 @@ struct Level {
   const uint4 *px16[2];   // GRD only: image v as the OTHER view's strip slots, H rows of Wp x 16 bytes {gradient (8 B), colour, colour of
                           // the next column towards larger disparity (x-1 in the right image, x+1 in the left image)} -- the exact
                           // LDS image of a strip slot, so the row engine moves it global -> LDS by DMA (cspm_rows.h)
+  const Pix8 *px8[2];     // GRD only: the packed 8-byte elements of kSrcGrd8 (raster sweep), H rows of Wp; null unless built
   const PixC *pc[2];      // H rows of Wp (fused-census source)
   const uint32_t *pix[2]; // packed colour only, H rows of Wp (pyramid construction, introspection)
   const double *grd[2];   // x-gradient only, H rows of Wp (GRD volume / max kernels); GRD only

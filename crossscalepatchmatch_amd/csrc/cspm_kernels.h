@@ -18,7 +18,11 @@
 #pragma once
 #include "cspm_device.h"
 
-// minimum waves per SIMD the register allocator leaves room for in the sweep kernel (2nd __launch_bounds__ argument)
+// minimum waves per SIMD the register allocator leaves room for in the sweep kernel (2nd __launch_bounds__ argument).  A sweep workgroup
+// is five waves (one per pyramid level), which the dispatcher places 2+1+1+1 on the CU's four SIMDs -- and the next workgroup the same
+// way: TWO resident workgroups per CU need FOUR wave slots on the first SIMD, i.e. <= 128 VGPRs (measured in round 5: at 137-155 VGPRs
+// only one workgroup per CU is resident and a sweep takes 38 ms instead of 20; it is also why 3 or 4 workgroups per CU never differed
+// from 2: at 95 VGPRs = 5 slots per SIMD the third workgroup would need a sixth).
 #ifndef CSPM_SWEEP_MINW
 #define CSPM_SWEEP_MINW 4
 #endif
@@ -326,6 +330,15 @@ __global__ void k_make_aos(const uint32_t *__restrict__ pix, const double *__res
   PixG e;
   e.pix = pix[i];
   e.g = grd ? grd[i] : 0.0;
+  out[i] = e;
+}
+// the packed 8-byte elements of the raster sweep (Level::px8, cspm_device.h Pix8); `bad` counts gradients that are not 36-bit multiples of
+// 2^-27 -- impossible for the gradient of an 8-bit image (cspm_device.h), checked all the same
+__global__ void k_make_px8(const uint32_t *__restrict__ pix, const double *__restrict__ grd, long long n, Pix8 *__restrict__ out, unsigned int *__restrict__ bad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Pix8 e;
+  if (!pix8_encode(pix[i], grd[i], &e)) atomicAdd(bad, 1u);
   out[i] = e;
 }
 // GRD strip slots of image v as the other view (Level::px16): {gradient, colour, colour of column x + dir}

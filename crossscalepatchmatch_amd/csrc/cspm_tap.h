@@ -54,9 +54,24 @@ __device__ __forceinline__ uint4 ld_elem(const char *base, int byte_off) {
   const u32x3 v = *reinterpret_cast<const u32x3_a4 *>(base + (size_t)(unsigned)byte_off);
   return uint4{v.x, v.y, v.z, 0u};
 }
-template <int SRC> constexpr int elem_size() { return SRC == kSrcCen ? 16 : 12; }
+template <int SRC> constexpr int elem_size() { return SRC == kSrcCen ? 16 : SRC == kSrcGrd8 ? 8 : 12; }
 template <int SRC>
 __device__ __forceinline__ uint32_t pix_of(const uint4 &v) { return SRC == kSrcCen ? v.w : v.z; }
+// kSrcGrd8 (cspm_device.h Pix8): one element = one dwordx2 load; TWO adjacent elements = one dwordx4 load (8-byte aligned)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+__device__ __forceinline__ uint2 ld_pix8(const char *base, int byte_off) {
+  const u32x2 v = *reinterpret_cast<const u32x2 *>(base + (size_t)(unsigned)byte_off);
+  return uint2{v.x, v.y};
+}
+__device__ __forceinline__ uint4 ld_pix8_pair(const char *base, int byte_off) {
+  const u32x4 v = *reinterpret_cast<const u32x4_a8 *>(base + (size_t)(unsigned)byte_off);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ uint32_t pix8_colour(uint32_t hi) { return hi >> 8; }
+// X = 2^52 + u: the biased, scaled gradient as an exact double (differences of two X are exact multiples of the gradient difference)
+__device__ __forceinline__ double pix8_x(uint32_t lo, uint32_t hi) { return __hiloint2double((int)((hi & 0xFu) | 0x43300000u), (int)lo); }
 __device__ __forceinline__ double g_of(const uint4 &v) { return __hiloint2double((int)v.y, (int)v.x); }
 
 // myCostGrd (cc/grd_cc.cpp:4-35) on one (own pixel, other pixel) pair; the border variant is the same
@@ -69,6 +84,13 @@ __device__ __forceinline__ double grd_cell(const double *lut_a, uint32_t Iq, dou
   const unsigned sad = min(__builtin_amdgcn_sad_u8(Iq, Io, 0u), kClrSat);
   const double grdDiff = __builtin_fmin(fabs(Gq - Go), 2.0);  // TAU_GRD
   return __builtin_fma(1 - 0.1, grdDiff, lut_a[sad]);         // ALPHA*clrDiff + (1-ALPHA)*grdDiff, contracted (device order)
+}
+// the same cell from packed elements: fabs(Gq - Go) = |Xq - Xo| * 2^-27 exactly, so min(|dG|, TAU_GRD) = 2^-27 * min(|dX|, 2^28) and
+// fma(1-ALPHA, grdDiff, clr) = fma((1-ALPHA) * 2^-27, min(|dX|, 2^28), clr): the product is the same real number, rounded once -- the bits of grd_cell()
+__device__ __forceinline__ double grd8_cell(const double *lut_a, uint32_t Iq, double Xq, uint32_t Io, double Xo) {
+  const unsigned sad = min(__builtin_amdgcn_sad_u8(Iq, Io, 0u), kClrSat);
+  const double dX = __builtin_fmin(fabs(Xq - Xo), 268435456.0);        // TAU_GRD * 2^27
+  return __builtin_fma((1 - 0.1) * 0x1p-27, dX, lut_a[sad]);
 }
 // CenCC cell (cc/cen_cc.cc:54-62): Hamming distance of the two 80-bit codes, CENCUS_BIT = 80 when the other view's
 // pixel is outside the image (pad cells carry bit 31 in `pix`)

@@ -118,6 +118,16 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
 #define CSPM_OPT_TABLE_VOLUMES 7
 #define CSPM_OPT_TABLE_VOLUMES_ACTIVE 8
 #define CSPM_OPT_VOLUME_FALLBACKS 9
+/* CSPM_OPT_SWEEP_PACKED (set before cspm_build_cost_grd; GRD with fused cells only; default 1): the raster sweep (SpatialPropagation,
+ * whose window taps are gathers) reads the level images as PACKED 8-byte pixels {36-bit fixed-point x-gradient, 24-bit colour} --
+ * lossless: the gradient of an 8-bit image's f32 gray values (grd_cc.cpp:70-77) is a multiple of 2^-27 below 256 -- so that a tap's two
+ * adjacent other-view pixels arrive with one 16-byte gather and its own pixel with one 8-byte gather (2 gathers / 24 B instead of
+ * 3 / 36 B per tap through the CU's L1).  Same cells, same order: identical planes.  0 = the 12-byte pixels every other kernel reads.
+ * CSPM_OPT_SWEEP_PACKED_ACTIVE (read only): 1 when the current cost object carries the packed pixels.
+ * CSPM_OPT_SWEEP_PACKED_BAD (read only; synchronises): pixels the packer could not represent exactly -- 0 by construction. */
+#define CSPM_OPT_SWEEP_PACKED 10
+#define CSPM_OPT_SWEEP_PACKED_ACTIVE 11
+#define CSPM_OPT_SWEEP_PACKED_BAD 12
 int cspm_get_option(cspm_ctx *ctx, int key, long long *value);
 int cspm_set_option(cspm_ctx *ctx, int key, long long value);
 /* The same constructors with `new CenCC` (main.cc:43-45; cc/cen_cc.cc:4-137): 9x9 census codes of every level built on

@@ -39,8 +39,20 @@ def odd_pair():
     return dict(l=l, r=r, gl=gl, gr=gr, w=77, h=41, max_dis=21)
 
 
+@pytest.fixture
+def gpu_ctx(_gpu_ctx_session):
+    """the session's context with its options back at the library defaults: StereoContext.build_cost_grd leaves an option alone
+    unless the test passes it, so a test that switched the table volumes off must not decide what the next one measures"""
+    from crossscalepatchmatch_amd import capi
+    ctx = _gpu_ctx_session
+    for key, value in ((capi.OPT_GRD_VOLUMES, 0), (capi.OPT_SWEEP_PAIRS, 0), (capi.OPT_TABLE_VOLUMES, 1), (capi.OPT_RASTER_LAUNCHES, 0),
+                       (capi.OPT_SWEEP_TIMEOUT_MS, 3000), (capi.OPT_SWEEP_PACKED, 1)):
+        ctx.set_option(key, value)
+    return ctx
+
+
 @pytest.fixture(scope="session")
-def gpu_ctx():
+def _gpu_ctx_session():
     # PyTorch bundles its own HIP runtime: when both live in one process, torch has to initialise first (bench.py and
     # batch.py do the same); libcspm_hip.so then binds to the runtime that is already loaded.
     try:

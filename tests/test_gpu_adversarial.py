@@ -153,3 +153,42 @@ def test_adversarial_plane_cost_batch(gpu_ctx):
                 got = gpu_ctx.plane_cost_batch(v, xy, np.concatenate([norm, param], 1))
                 want = np.array([pc.cost(xy[i, 0], xy[i, 1], norm[i], param[i], v, po.SUM_DEVICE) for i in range(n)])
                 np.testing.assert_array_equal(got, want, err_msg=f"{kind} scale_num {sn} lambda {lam} view {v}")
+
+
+@pytest.mark.parametrize("kind", ["saturated", "stripes", "identical", "white", "noise"])
+def test_sweep_packed_pixels_equal_the_12_byte_pixels(gpu_ctx, kind):
+    """The raster sweep reads packed 8-byte pixels {36-bit fixed-point gradient, colour} (CSPM_OPT_SWEEP_PACKED, the default); every
+    other kernel and cspm_plane_cost_batch read the 12-byte pixels {f64 gradient, colour}.  Lossless by construction: no pixel may
+    be reported unrepresentable, and the sweep must give the same planes and costs either way -- on the inputs with the largest
+    gradients (0/255 stripes and blocks), on noise, cross-scale and single scale, persistent and per-diagonal sweeps."""
+    from crossscalepatchmatch_amd import capi
+    if kind == "noise":
+        l, r = synth.make_pair(W, H, D, regions=3, seed=12)[:2]
+    else:
+        l, r = synth.make_adversarial(kind, W, H, D, seed=11)
+    for sn, lam in ((5, 0.3), (0, 0.0)):
+        out = []
+        for packed, launches in ((1, 0), (0, 0), (1, 1)):
+            try:
+                gpu_ctx.set_option(capi.OPT_SWEEP_PACKED, packed)
+                gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, launches)
+                gpu_ctx.set_images(l, r)
+                gpu_ctx.build_cost_grd(D, 35, sn, lam)
+                assert gpu_ctx.get_option(capi.OPT_SWEEP_PACKED_ACTIVE) == packed
+                assert gpu_ctx.get_option(capi.OPT_SWEEP_PACKED_BAD) == 0
+                gpu_ctx.patchmatch(2, seed=6, schedule=po.SCHED_RASTER)
+                out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+            finally:
+                gpu_ctx.set_option(capi.OPT_SWEEP_PACKED, 1)
+                gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
+        for k in (1, 2):
+            for v in (0, 1):
+                np.testing.assert_array_equal(out[0][v][0], out[k][v][0], err_msg=f"{kind} scale_num {sn} variant {k} view {v}")
+                np.testing.assert_array_equal(out[0][v][1], out[k][v][1], err_msg=f"{kind} scale_num {sn} variant {k} view {v}")
+        # the stored costs (written by the sweep from packed pixels, by the row kernels from strips) are what cspm_plane_cost_batch
+        # computes from the 12-byte pixels
+        rng = np.random.default_rng(2)
+        ys, xs = rng.integers(0, H, 200), rng.integers(0, W, 200)
+        for v in (0, 1):
+            npar, cost = out[0][v]
+            np.testing.assert_array_equal(gpu_ctx.plane_cost_batch(v, np.stack([xs, ys], 1), npar[ys, xs]), cost[ys, xs])

@@ -220,24 +220,67 @@ def test_c3_whole_pair_bit_exact(gpu_ctx, c3):
     assert synth.bad_fraction(gpu_ctx.disparity_f64(0), gl, 2.0) < 0.2
 
 
-def test_north_star_bar_c3_crop_reference_order(gpu_ctx, c3):
-    """The north-star bar on the headline configuration's content: a centred 320-column crop of the C3 pair at full height and full
-    disparity range (1242x375 -> 320x375, max_dis 128, 5 levels; a CROP, because the reference order keeps the raster sweep serial
-    and the whole pair would take four minutes more) on the GPU against the CPU oracle in the REFERENCE order (serial raster sweep,
-    serial window sum, no FMA), identical inputs and random numbers: >= 99.5 % of the pixels of both views within 0.5 px."""
+def test_north_star_bar_c3_whole_pair_reference_order(gpu_ctx, c3):
+    """The north-star bar on the WHOLE headline pair (round-4 review, Weak 3: until now only a 320-column crop was compared in the
+    reference order): 1242x375, max_dis 128, 5 levels, on the GPU (device order) against the CPU oracle in the REFERENCE order
+    (serial window sum, no FMA, the reference's raster traversal), identical inputs and random numbers: >= 99.5 % of all
+    2 x 465 750 pixels within 0.5 px.  The oracle walks the reference's raster sweep anti-diagonal by anti-diagonal here
+    (`wavefront`: the same in-place serial result, tests/test_oracle_primitives.py) so that the sweep uses the host's cores too;
+    bench.py's cpu_baseline leg repeats this comparison with the sweep serial, as the reference runs it."""
     cfg, l, r, _, _ = c3
-    x0 = (cfg["w"] - 320) // 2
-    lc, rc = np.ascontiguousarray(l[:, x0:x0 + 320]), np.ascontiguousarray(r[:, x0:x0 + 320])
-    gpu_ctx.set_images(lc, rc)
+    gpu_ctx.set_images(l, r)
     gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
     gpu_ctx.patchmatch(3, seed=12345, schedule=0)
-    pc = po.PlaneCost(lc, rc, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
-    pm = po.PatchMatch(lc, rc, cfg["max_dis"], cfg["dis_scale"])
-    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+    pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
+    pm.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL, wavefront=True)
     for v in (0, 1):
         d = np.abs(gpu_ctx.disparity_f64(v) - pm.disp_f64(v))
         within = float(np.mean(d <= 0.5))
+        assert d.shape == (375, 1242)
         assert within >= 0.995, (v, within, float(d.max()))
+
+
+def test_c5_shaped_crop_d256_whole_pipeline_bit_exact(gpu_ctx):
+    """BASELINE.json configs[4]'s shape, oracle-checked (round-4 review, Weak 4: C5's PatchMatch was only self-checked): a 704x160
+    window of the C5 pair at its full disparity range -- max_dis 256, 5 levels, lambda 0.3, use_pp -- through the whole pipeline
+    against the oracle in the device order: 356-slot level-0 strips (13.8 KB of LDS per wave, the LDS opt-in), DMA-filled tables
+    from D = 256 volumes, ranges that span up to 256 disparities, 11 halving steps of refinement, then post-processing.
+    array_equal on planes, stored costs, raw and post-processed maps.  ~1.5e10 window taps on the host."""
+    from crossscalepatchmatch_amd import capi
+    cfg, l, r, _, _ = synth.make_config("C5")
+    y0, x0, w, h = 600, 1000, 704, 160
+    lc, rc = np.ascontiguousarray(l[y0:y0 + h, x0:x0 + w]), np.ascontiguousarray(r[y0:y0 + h, x0:x0 + w])
+    D = cfg["max_dis"]
+    assert D == 256 and cfg["scale_num"] == 5 and cfg["use_pp"]
+    gpu_ctx.set_images(lc, rc)
+    gpu_ctx.build_cost_grd(D, 35, cfg["scale_num"], cfg["reg_lambda"])
+    assert gpu_ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 1
+    assert [gpu_ctx.level_dims(s)[2] for s in range(5)] == [256, 128, 64, 32, 16]
+    gpu_ctx.patchmatch(2, seed=7, schedule=0)
+    pc = po.PlaneCost(lc, rc, D, 35, cfg["scale_num"], cfg["reg_lambda"])
+    pm = po.PatchMatch(lc, rc, D, cfg["dis_scale"])
+    pm.run(2, pc, False, seed=7, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE, wavefront=True)
+    for v in (0, 1):
+        npar, cost = gpu_ctx.get_planes(v)
+        P = pm.planes(v)
+        np.testing.assert_array_equal(npar[..., :3], P[..., 0:3], err_msg=f"normals, view {v}")
+        np.testing.assert_array_equal(npar[..., 3:], P[..., 6:9], err_msg=f"plane parameters, view {v}")
+        np.testing.assert_array_equal(cost, pm.min_cost(v), err_msg=f"stored costs, view {v}")
+        np.testing.assert_array_equal(gpu_ctx.disparity_u8(v, cfg["dis_scale"]), pm.dis(v), err_msg=f"8-bit map, view {v}")
+    pm.postprocess()
+    lo, ro = gpu_ctx.postprocess(cfg["dis_scale"])
+    np.testing.assert_array_equal(lo, pm.dis(0), err_msg="post-processed left map")
+    np.testing.assert_array_equal(ro, pm.dis(1), err_msg="post-processed right map")
+    # the same crop with computed tables (what a pair too large for the volumes gets): identical
+    want = [gpu_ctx.get_planes(v) for v in (0, 1)]
+    gpu_ctx.build_cost_grd(D, 35, cfg["scale_num"], cfg["reg_lambda"], table_volumes=False)
+    gpu_ctx.patchmatch(2, seed=7, schedule=0)
+    for v in (0, 1):
+        npar, cost = gpu_ctx.get_planes(v)
+        np.testing.assert_array_equal(npar, want[v][0])
+        np.testing.assert_array_equal(cost, want[v][1])
+    gpu_ctx.build_cost_grd(D, 35, cfg["scale_num"], cfg["reg_lambda"], table_volumes=True)  # leave the shared context on its default
 
 
 def test_c3_computed_tables_equal_dma_filled_tables(gpu_ctx, c3):

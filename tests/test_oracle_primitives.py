@@ -143,3 +143,38 @@ def test_wavefront_sweep_is_the_serial_sweep(odd_pair, scale_num, lam, sum_order
     for a, b in zip(out[0][:4], out[1][:4]):
         np.testing.assert_array_equal(a, b)
     assert out[0][4] == out[1][4]
+
+
+def test_f32_gray_of_every_colour_is_a_multiple_of_2_pow_minus_27():
+    """What the packed 8-byte pixels of the raster sweep rest on (csrc/cspm_device.h Pix8): the GRD x-gradient is
+    gray[x+1] - gray[x-1] of the f32 gray image (grd_cc.cpp:70-77), so if EVERY f32 gray value of an 8-bit colour is a multiple of
+    2^-27 in [0, 256), every gradient is a multiple of 2^-27 in (-256, 256): 36 bits, exactly.  All 2^24 colours, through the
+    oracle's own RGB2GRAY restatement; then the encode / decode arithmetic of the device restated in numpy on random gradients."""
+    L = po.lib()
+    chunk = 1 << 20
+    base = np.arange(chunk, dtype=np.int64)
+    gmax = 0.0
+    for hi in range(16):
+        c = base + hi * chunk
+        rgb = np.stack([c & 255, (c >> 8) & 255, (c >> 16) & 255], 1).astype(np.float64)
+        gray = np.zeros(chunk, np.float32)
+        L.csor_rgb2gray_f32(rgb.ctypes.data_as(C.POINTER(C.c_double)), chunk, 1, gray.ctypes.data_as(C.POINTER(C.c_float)))
+        g = gray.astype(np.float64)
+        s = g * 2.0 ** 27
+        assert np.all(s == np.rint(s)) and g.min() >= 0.0 and g.max() < 256.0
+        gmax = max(gmax, float(g.max()))
+    assert gmax > 254.9
+    # encode (cspm_device.h pix8_encode) / decode (cspm_tap.h pix8_x, grd8_cell) on random pairs of such gradients
+    rng = np.random.default_rng(1)
+    ga = rng.integers(-(2 ** 35) + 1, 2 ** 35, 100000).astype(np.float64) * 2.0 ** -27
+    gb = rng.integers(-(2 ** 35) + 1, 2 ** 35, 100000).astype(np.float64) * 2.0 ** -27
+    gb[:1000] = ga[:1000] + rng.integers(-3, 4, 1000) * 2.0 ** -27  # near-equal gradients: the untruncated branch
+    ua, ub = (ga * 2.0 ** 27 + 2.0 ** 35).astype(np.uint64), (gb * 2.0 ** 27 + 2.0 ** 35).astype(np.uint64)
+    assert ua.max() < 2 ** 36 and ub.max() < 2 ** 36
+    xa = ((np.uint64(0x43300000) << np.uint64(32)) | ua).view(np.float64)
+    xb = ((np.uint64(0x43300000) << np.uint64(32)) | ub).view(np.float64)
+    np.testing.assert_array_equal(xa - 2.0 ** 52, ua.astype(np.float64))
+    packed = np.minimum(np.abs(xa - xb), 2.0 ** 28)                # min(|dX|, TAU_GRD * 2^27)
+    plain = np.minimum(np.abs(ga - gb), 2.0)                       # min(|dG|, TAU_GRD), grd_cc.cpp:14-17
+    np.testing.assert_array_equal(packed * 2.0 ** -27, plain)      # the same number; the factor folds into the cell's fma constant
+    assert ((1 - 0.1) * 2.0 ** -27) * 2.0 ** 27 == (1 - 0.1)       # (1-ALPHA) * 2^-27 is an exact scaling of (1-ALPHA)

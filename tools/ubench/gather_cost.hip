@@ -29,7 +29,13 @@ __global__ __launch_bounds__(320) void k_gather(const char *base, int pitch_elem
           typedef u3 u3a __attribute__((aligned(4)));
           const u3 v = *reinterpret_cast<const u3a *>(a);
           acc += v.x ^ v.y ^ v.z;
-        } else { const uint4 v = *reinterpret_cast<const uint4 *>(a); acc += v.x ^ v.y ^ v.z ^ v.w; }
+        } else if constexpr (BYTES == 16) { const uint4 v = *reinterpret_cast<const uint4 *>(a); acc += v.x ^ v.y ^ v.z ^ v.w; }
+        else {  // BYTES == 816: 8-byte elements, 16-byte loads of two neighbours -- half of the addresses are only 8-byte aligned
+          typedef unsigned u4 __attribute__((ext_vector_type(4)));
+          typedef u4 u4a __attribute__((aligned(8)));
+          const u4 v = *reinterpret_cast<const u4a *>(base + ((size_t)row * pitch_elems + col) * 8);
+          acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
       }
     }
     ox = (ox + 1) % (pitch_elems - 64);
@@ -98,7 +104,7 @@ static void run(const char *d, int pitch, int rows, unsigned *dout, int wg_per_c
   const double gathers_per_cu = (double)wg_per_cu * 5 * n * 20;  // waves per workgroup x items x gathers per item
   const double ns = ms * 1e6 / gathers_per_cu;
   printf("%-28s %d workgroups/CU: %7.2f ms, %6.1f ns = %6.1f cycles (2.4 GHz) per gather and CU, %5.1f B/cycle/CU\n", name, wg_per_cu, ms, ns, ns * 2.4,
-         63.0 * BYTES / (ns * 2.4));
+         63.0 * (BYTES == 816 ? 16 : BYTES) / (ns * 2.4));
 }
 
 int main() {
@@ -113,6 +119,7 @@ int main() {
     run<8>(d, pitch, rows, dout, wg, "dwordx2 (8 B elements)");
     run<12>(d, pitch, rows, dout, wg, "dwordx3 (12 B elements)");
     run<16>(d, pitch, rows, dout, wg, "dwordx4 (16 B elements)");
+    run<816>(d, pitch, rows, dout, wg, "dwordx4 of two 8 B elements");
     run_dma(d, pitch, rows, dout, wg);
   }
   return 0;
