@@ -22,9 +22,10 @@ OPT_SWEEP_PAIRS = 5          # paired-cell volumes for the raster sweep: 0 never
 OPT_SWEEP_PAIRS_ACTIVE = 6   # read only
 OPT_TABLE_VOLUMES = 7        # device-cell volumes for the row kernels' DMA-filled tables: 1 when they fit (default), 0 never
 OPT_TABLE_VOLUMES_ACTIVE = 8 # read only
-OPT_SWEEP_PACKED = 10        # packed 8-byte pixels for the raster sweep (default 1)
+OPT_SWEEP_PACKED = 10        # packed 8-byte pixels for the raster sweep (default 0: measured slower)
 OPT_SWEEP_PACKED_ACTIVE = 11 # read only
 OPT_SWEEP_PACKED_BAD = 12    # read only, synchronises: pixels the packer could not represent (0 by construction)
+OPT_SWEEP_FLOW = 13          # persistent raster sweep scheduled by dataflow (1: measured slower) or by ordered claims (0, default)
 OPT_VOLUME_FALLBACKS = 9     # read only: hipMalloc failures of an optional volume this context survived
 
 # every symbol include/cspm.h declares

@@ -55,7 +55,7 @@ struct cspm_ctx {
   // persistent sweep: workgroups launched per CU (env CSPM_SWEEP_WG).  2..6 take the same time when the pair is alone (the sweep
   // is bound by its dependency chain; 1 is 43 % slower); the resident workgroups mostly wait, and every one of them holds
   // registers another pair's refinement could use: with three pairs in flight 2 gives 222.7 ms per pair, 3 gives 228.1.
-  int sweep_wg_per_cu = 2;
+  int sweep_wg_per_cu = 0;           // 0 = the default, 2: a CU evaluates two sweep pixels at full speed -- with three resident AND computing (the dataflow sweep) a pixel takes 23 us instead of 9
   int sweep_bands = 1;               // row bands of the persistent sweep (env CSPM_SWEEP_BANDS, up to 8; 1 = one queue for the whole image: the default,
                                      // bands help only the paired-cell volumes)
   int sweep_bands_built = 0;         // what d_sweep_start was filled for
@@ -89,7 +89,8 @@ struct cspm_ctx {
   bool sweep_pairs = false;      // this cost object carries Level::vol2: the raster sweep reads paired cells (kSrcVol2)
   long long opt_table_volumes = 1;          // CSPM_OPT_TABLE_VOLUMES: device-cell volumes for the row engine's DMA-filled tables, when they fit
   long long table_volumes_limit = 48LL << 30; // bytes of such volumes a context may hold (env CSPM_TABLE_VOLUMES_MAX_MB): 288 GB of HBM per GPU, a few contexts in flight
-  long long opt_sweep_packed = 1;           // CSPM_OPT_SWEEP_PACKED: the raster sweep of a fused GRD cost reads packed 8-byte elements (kSrcGrd8); 0 = the 12-byte elements
+  long long opt_sweep_packed = 0;           // CSPM_OPT_SWEEP_PACKED: 1 = the raster sweep of a fused GRD cost reads packed 8-byte elements (kSrcGrd8); 0 (default: measured
+                                            // 8 % slower -- the sweep is latency-bound and the unpacking adds VALU work to every step) = the 12-byte elements
   bool sweep_packed = false;                // this cost object carries Level::px8
   unsigned int *d_px8_bad = nullptr;        // device counter: gradients k_make_px8 could not pack (must stay 0)
   double volumes_mem_fraction = 0.5;        // of the memory hipMemGetInfo reports free when a cost object is allocated, the share the optional volumes (cvol, vol2) may take (env CSPM_VOLUMES_MEM_FRACTION)
@@ -110,6 +111,9 @@ struct cspm_ctx {
   // persistent raster sweep (k_spatial_sweep)
   unsigned int *d_sweep_ctrl = nullptr, *d_sweep_start = nullptr;
   unsigned long long *d_sweep_gran = nullptr;  // persistent sweep: 12 data-tagged granules per pixel and view (cspm_chain.h)
+  unsigned int *d_sweep_ready = nullptr, *d_sweep_qctl = nullptr;  // dataflow sweep (k_spatial_flow): final predecessors per pixel; queue control words
+  unsigned long long *d_sweep_queue = nullptr;                      // ... and its queue of ready pixels
+  long long opt_sweep_flow = 0;  // CSPM_OPT_SWEEP_FLOW: 1 = the persistent raster sweep is scheduled by dataflow (k_spatial_flow), 0 (default: measured faster) = by ordered claims (k_spatial_sweep)
   unsigned int sweep_epoch = 0;
   long long opt_raster_launches = 0;  // CSPM_OPT_RASTER_LAUNCHES
   long long sweep_timeout_ms = 3000;  // CSPM_OPT_SWEEP_TIMEOUT_MS (env CSPM_SWEEP_TIMEOUT_MS): bound of one wait for a predecessor pixel
@@ -285,6 +289,11 @@ void free_field(cspm_ctx *c) {
   if (c->d_sweep_ctrl) (void)hipFree(c->d_sweep_ctrl);
   if (c->d_sweep_gran) (void)hipFree(c->d_sweep_gran);
   if (c->d_sweep_start) (void)hipFree(c->d_sweep_start);
+  if (c->d_sweep_ready) (void)hipFree(c->d_sweep_ready);
+  if (c->d_sweep_qctl) (void)hipFree(c->d_sweep_qctl);
+  if (c->d_sweep_queue) (void)hipFree(c->d_sweep_queue);
+  c->d_sweep_ready = c->d_sweep_qctl = nullptr;
+  c->d_sweep_queue = nullptr;
   c->d_sweep_ctrl = c->d_sweep_start = nullptr;
   c->d_sweep_gran = nullptr;
   c->field_mem = nullptr;
@@ -642,6 +651,12 @@ int ensure_field(cspm_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, (2 + kSweepMaxBands) * sizeof(unsigned int), c->stream));
   if ((rc = dalloc(c, &c->d_sweep_gran, 2 * n * kGranPerPixel, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_gran, 0, sizeof(unsigned long long) * 2 * n * kGranPerPixel, c->stream));
+  // dataflow sweep: predecessor counters (zeroed before every sweep), the queue of ready pixels (epoch-tagged entries: never cleared;
+  // at most one entry per pixel plus one reserved slot per waiting workgroup) and its control words
+  if ((rc = dalloc(c, &c->d_sweep_ready, 2 * n, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->d_sweep_queue, 2 * n + 65536, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_queue, 0, sizeof(unsigned long long) * (2 * n + 65536), c->stream));
+  if ((rc = dalloc(c, &c->d_sweep_qctl, 4, nullptr))) return rc;
   c->sweep_epoch = 0;
   {
     // per row band b (sweep rows [b*H/nb, (b+1)*H/nb)): start[k] = the band's items (both views) on anti-diagonals < k
@@ -820,7 +835,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
 #ifdef CSPM_SWEEP_TRACE
     {
       static long long *d_trace = nullptr;
-      if (!d_trace) (void)hipMalloc((void **)&d_trace, sizeof(long long) * kTraceSlots * (size_t)sw.total);
+      if (!d_trace) { (void)hipMalloc((void **)&d_trace, sizeof(long long) * kTraceSlots * (size_t)sw.total); (void)hipMemset(d_trace, 0, sizeof(long long) * kTraceSlots * (size_t)sw.total); }
       sw.trace = d_trace;
       if (const char *path = getenv("CSPM_SWEEP_TRACE_FILE")) {
         static int sweep_no = 0;
@@ -835,15 +850,26 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     }
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl + 2, 0, kSweepMaxBands * sizeof(unsigned int), c->stream));  // the claim counters; ctrl[1] is sticky
+    const bool flow = c->opt_sweep_flow != 0 && (long long)c->W * c->H < (1LL << 30);
+    if (flow) {
+      sw.ready[0] = c->d_sweep_ready;
+      sw.ready[1] = c->d_sweep_ready + (size_t)c->W * c->H;
+      sw.queue = c->d_sweep_queue;
+      sw.qctl = c->d_sweep_qctl;
+      HIPCHK(c, hipMemsetAsync(c->d_sweep_ready, 0, sizeof(unsigned int) * 2 * (size_t)c->W * c->H, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->d_sweep_qctl, 0, 4 * sizeof(unsigned int), c->stream));
+    }
     int ncu = c->ncu;
+    const int wg_per_cu = c->sweep_wg_per_cu > 0 ? c->sweep_wg_per_cu : 2;
     // more workgroups than fit is harmless (unclaimed work is all a late workgroup needs); at least one per band, a multiple of
     // the bands so that every band gets the same number
-    unsigned grid = (unsigned)std::max<long long>(sw.nbands, std::min<long long>((long long)sw.total, (long long)ncu * c->sweep_wg_per_cu));
+    unsigned grid = (unsigned)std::max<long long>(sw.nbands, std::min<long long>((long long)sw.total, (long long)ncu * wg_per_cu));
     grid = (grid + (unsigned)sw.nbands - 1) / (unsigned)sw.nbands * (unsigned)sw.nbands;
     const unsigned waves = sweep_waves(c);
     {
       Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
-      LAUNCH_SWEEP(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
+      if (flow) LAUNCH_SWEEP(k_spatial_flow, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
+      else LAUNCH_SWEEP(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
     }
     c->sweep_pending = true;
   } else {
@@ -991,6 +1017,7 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_TABLE_VOLUMES")) c->opt_table_volumes = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_TABLE_VOLUMES_MAX_MB")) c->table_volumes_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_PACKED")) c->opt_sweep_packed = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_SWEEP_FLOW")) c->opt_sweep_flow = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
   if (const char *e = getenv("CSPM_FAULT_VOLUME_ALLOC")) c->fault_volume_alloc = atoi(e);
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
@@ -1107,6 +1134,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_SWEEP_PAIRS: c->opt_sweep_pairs = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_TABLE_VOLUMES: c->opt_table_volumes = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: c->opt_sweep_packed = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_FLOW: c->opt_sweep_flow = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -1128,6 +1156,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
+    case CSPM_OPT_SWEEP_FLOW: *value = c->opt_sweep_flow; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED_ACTIVE: *value = c->sweep_packed ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED_BAD: {  // synchronises: gradients the packer could not represent (always 0 for 8-bit images)
       if (!c->cost_alloc || !c->d_px8_bad) { *value = 0; return CSPM_OK; }

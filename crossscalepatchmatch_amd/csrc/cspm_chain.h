@@ -75,6 +75,7 @@ __device__ __forceinline__ ChainLevel make_chain_level(const Cost &cd, int s, in
     A.px = reinterpret_cast<const char *>(L.px[view]); A.opx = reinterpret_cast<const char *>(L.px[1 - view]);
     A.Ip = L.px[view][cy * L.Wp + L.pad + cx].pix;
   }
+  A.Ip = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.Ip);  // the window centre's colour: one value per wave
   A.sgn = view == 0 ? -1.0 : 1.0;
   A.dirE = view == 0 ? -E : E;  // left view looks at x-d in the right image, right view at x+d in the left
   A.vol = L.vol[view];
@@ -106,22 +107,34 @@ __device__ __forceinline__ unsigned long long step_stamp(unsigned dep0, unsigned
 // bookkeeping (profiles/r05_sweep_step_budget.txt) -- and the raster sweep is 1 616 dependent pixel evaluations of 20 such steps
 // each.  The gathers of step st+1 (and of the next pass's first step) depend on nothing step st computes: they are issued BEFORE
 // step st is consumed, so their round trip hides behind its arithmetic.  Same operations, same order of every sum: identical bits.
-#ifndef CSPM_CHAIN_PIPE
-#define CSPM_CHAIN_PIPE 1
+// MEASURED (profiles/r05_sweep_*): a sweep pixel's evaluation drops from 8.3 to 6.3 us -- and the sweep takes the same 20 ms: its anti-
+// diagonals advance at the pace of the SLOWEST pixels on the critical path through the dependency lattice (two-candidate pixels,
+// hand-over), not of the median one, and the pipelined kernel needs 97-109 VGPRs against 81, which other pairs' kernels would use.
+// So the raster sweep keeps the plain loop (CSPM_SWEEP_PIPE = 0); single evaluations (cspm_plane_cost_batch, the red-black option)
+// run the pipelined one, which keeps it compiled and tested: two schedules of the same arithmetic that must agree bit for bit.
+#ifndef CSPM_SWEEP_PIPE
+#define CSPM_SWEEP_PIPE 0
 #endif
+
+// a value that is the same in every lane of the wave (the candidate planes of a pixel, the window centre's colour): telling the compiler
+// so moves it to scalar registers -- the software-pipelined steps need the vector registers (two workgroups of five waves are resident
+// per CU above 96 VGPRs, three at or below: tools/ubench/residency.hip)
+__device__ __forceinline__ double wave_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 // One level, NC candidates (1 or 2) at the same pixel: the plane-independent half of every tap (own element, guide
 // weight) is computed once.  `pass_first/pass_step` let several waves share the passes of one level (single-scale sweep).
 // The chain sums go straight into LDS: part[c][pass * 64 + lane] (round 5: no S[NC][passes] register array, a run-time pass loop --
 // the software-pipelined steps need the registers); finish_level() turns them into the level sum.
-template <int SRC, int NC>
+template <int SRC, int NC, bool PIPE = false>
 __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A, const Luts &lut, const ChainPlane (&pl)[NC], int lane,
                                              int pass_first, int pass_step, double *const (&part)[NC]) {
   constexpr int E = SRC == kSrcVol2 ? 4 : elem_size<SRC>();
   const int lutzero = kLutZero;
   const int lr = lane / kRowMod, j = lane - lr * kRowMod;  // lane 63: lr = 9 -> never a valid chain
-#if CSPM_CHAIN_PIPE && !defined(CSPM_STEP_TRACE)
-  if constexpr (SRC == kSrcGrd || SRC == kSrcCen || SRC == kSrcGrd8) {
+#if !defined(CSPM_STEP_TRACE)
+  if constexpr (PIPE && (SRC == kSrcGrd || SRC == kSrcCen || SRC == kSrcGrd8)) {
     struct PassCtx {
       bool chain_ok;
       int ob;          // byte offset of the chain's first tap
@@ -384,10 +397,10 @@ __device__ __forceinline__ double eval_plane_chain(const Cost &cd, const Luts &l
     double a = pa, b = pb, c = pc;
     if (CS) plane_param(nx, ny, nz, (double)cur_x, (double)cur_y, cur_disp, a, b, c);  // :144-149
     const ChainLevel A = make_chain_level<SRC>(cd, s, view, cur_x, cur_y);
-    const ChainPlane pl[1] = {{a, b, c}};
+    const ChainPlane pl[1] = {{wave_uniform(a), wave_uniform(b), wave_uniform(c)}};
     double *const parts[1] = {m.part[0]};
     wave_lds_fence();  // the previous level's reads of part[] are done
-    chain_passes<SRC, 1>(cd, A, lut, pl, lane, 0, 1, parts);
+    chain_passes<SRC, 1, true>(cd, A, lut, pl, lane, 0, 1, parts);
     wave_lds_fence();
     const double sc = finish_level(A, m.part[0], lane);
     if (CS) cost += sc * cd.lv[s].wgt;  // :182
@@ -493,9 +506,23 @@ __device__ __forceinline__ SweepShared sweep_shared(unsigned char *smem) {
 
 // Both candidate costs at pixel (x,y) of view v; every wave of the workgroup calls it.  `both` = the two candidates differ
 // (otherwise only c0 is evaluated and cost1 = cost0).  Results are valid in wave 0 after the call.
+// the plane-independent part of a sweep pixel's evaluation: this wave's level (cross-scale) or level 0, its window geometry, the window
+// centre's colour (a global load) and max_cost (a scalar load).  The persistent sweep computes it BEFORE it waits for the predecessors'
+// planes, so those loads and the address arithmetic overlap the wait instead of following it (0.7 us of every pixel, profiles/r05_sweep_step_budget.txt)
+template <bool CS, int SRC>
+__device__ __forceinline__ ChainLevel sweep_level_setup(const Cost &cd, int v, int x, int y, int wave) {
+  if (CS) {
+    const int level = wave / kSweepWpl;
+    int cur_x = x, cur_y = y;
+    for (int s = 0; s < level; ++s) { cur_y /= 2; cur_x /= 2; }
+    return make_chain_level<SRC>(cd, level < cd.levels ? level : 0, v, cur_x, cur_y);
+  }
+  return make_chain_level<SRC>(cd, 0, v, x, y);
+}
+
 template <bool CS, int SRC>
 __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut, const SweepShared &sh, int v, int x, int y, const Cand &c0,
-                                                const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1) {
+                                                const Cand &c1, bool both, int wave, int lane, double &cost0, double &cost1, const ChainLevel &A) {
   if (CS) {
     // kSweepWpl waves per pyramid level share its chain passes (a sweep pixel is latency-bound: its evaluation is on the
     // critical path of the whole sweep).  Level of this wave: (cur_x, cur_y, cur_disp) after `level` halvings
@@ -504,16 +531,17 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
     double d0 = c0.a * (double)x + c0.b * (double)y + c0.c, d1 = c1.a * (double)x + c1.b * (double)y + c1.c;
     int cur_x = x, cur_y = y;
     for (int s = 0; s < level; ++s) { cur_y /= 2; cur_x /= 2; d0 /= 2.0; d1 /= 2.0; }
-    const ChainLevel A = make_chain_level<SRC>(cd, level < cd.levels ? level : 0, v, cur_x, cur_y);
     double *part0 = sh.m[level * kSweepWpl].part[0], *part1 = sh.m[level * kSweepWpl].part[1];  // the level's first wave's scratch serves all its waves
     if (level < cd.levels) {
       ChainPlane pl[2];
       plane_param(c0.nx, c0.ny, c0.nz, (double)cur_x, (double)cur_y, d0, pl[0].a, pl[0].b, pl[0].c);  // :144-149
+      pl[0].a = wave_uniform(pl[0].a); pl[0].b = wave_uniform(pl[0].b); pl[0].c = wave_uniform(pl[0].c);
       if (both) {
         plane_param(c1.nx, c1.ny, c1.nz, (double)cur_x, (double)cur_y, d1, pl[1].a, pl[1].b, pl[1].c);
+        pl[1].a = wave_uniform(pl[1].a); pl[1].b = wave_uniform(pl[1].b); pl[1].c = wave_uniform(pl[1].c);
         EVAL_STAMP(4);
         double *const parts[2] = {part0, part1};
-        chain_passes<SRC, 2>(cd, A, lut, pl, lane, part_of, kSweepWpl, parts);
+        chain_passes<SRC, 2, CSPM_SWEEP_PIPE != 0>(cd, A, lut, pl, lane, part_of, kSweepWpl, parts);
         EVAL_STAMP(5);
         if (kSweepWpl == 1) {
           wave_lds_fence();
@@ -524,7 +552,7 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
       } else {
         const ChainPlane p1[1] = {pl[0]};
         double *const parts[1] = {part0};
-        chain_passes<SRC, 1>(cd, A, lut, p1, lane, part_of, kSweepWpl, parts);
+        chain_passes<SRC, 1, CSPM_SWEEP_PIPE != 0>(cd, A, lut, p1, lane, part_of, kSweepWpl, parts);
         if (kSweepWpl == 1) {
           wave_lds_fence();
           const double s0 = finish_level(A, part0, lane);
@@ -556,15 +584,14 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
   } else {
     // single scale: the waves share the passes of the one level; chain sums meet in wave 0's scratch
     const int nw = (int)(blockDim.x >> 6);
-    const ChainLevel A = make_chain_level<SRC>(cd, 0, v, x, y);
-    const ChainPlane pl[2] = {{c0.a, c0.b, c0.c}, {c1.a, c1.b, c1.c}};
+    const ChainPlane pl[2] = {{wave_uniform(c0.a), wave_uniform(c0.b), wave_uniform(c0.c)}, {wave_uniform(c1.a), wave_uniform(c1.b), wave_uniform(c1.c)}};
     double *const parts[2] = {sh.m[0].part[0], sh.m[0].part[1]};  // the chain sums of all waves meet in wave 0's scratch
     if (both) {
-      chain_passes<SRC, 2>(cd, A, lut, pl, lane, wave, nw, parts);
+      chain_passes<SRC, 2, CSPM_SWEEP_PIPE != 0>(cd, A, lut, pl, lane, wave, nw, parts);
     } else {
       const ChainPlane p1[1] = {pl[0]};
       double *const parts1[1] = {parts[0]};
-      chain_passes<SRC, 1>(cd, A, lut, p1, lane, wave, nw, parts1);
+      chain_passes<SRC, 1, CSPM_SWEEP_PIPE != 0>(cd, A, lut, p1, lane, wave, nw, parts1);
     }
     __syncthreads();
     cost0 = cost1 = 0.0;
@@ -599,7 +626,8 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave) void k_spatial_diag(Cost cd,
   const Cand c1{f.nx[j1], f.ny[j1], f.nz[j1], f.a[j1], f.b[j1], f.c[j1]};
   const bool same01 = c0.nx == c1.nx && c0.ny == c1.ny && c0.nz == c1.nz && c0.a == c1.a && c0.b == c1.b && c0.c == c1.c;
   double cost0, cost1;
-  eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, have0 && have1 && !same01, wave, lane, cost0, cost1);
+  const ChainLevel A = sweep_level_setup<CS, SRC>(cd, v, x, y, wave);
+  eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, have0 && have1 && !same01, wave, lane, cost0, cost1, A);
   if (threadIdx.x == 0) {
     double best_cost = f.cost[i];
     int pick = -1;
@@ -650,6 +678,10 @@ struct Sweep {
   unsigned int epoch, total;
   long long timeout_ticks;  // bound of one wait for a predecessor, in ticks of the 100 MHz constant clock
   long long *trace;  // debug (-DCSPM_SWEEP_TRACE): 8 wall-clock stamps per item
+  // dataflow scheduling (k_spatial_flow)
+  unsigned int *ready[2];       // per view and pixel: how many of its predecessors are final (zeroed before the launch)
+  unsigned long long *queue;    // ready pixels nobody continued into: {epoch, view * W * H + pixel}, data-tagged like the granules
+  unsigned int *qctl;           // [0] slots reserved by poppers, [1] slots filled by pushers, [2] views whose last pixel is final
 };
 #ifdef CSPM_SWEEP_TRACE
 #define SWEEP_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[((size_t)2 * pm.W * by0 + item) * kTraceSlots + (slot)] = wall_clock64(); } while (0)
@@ -719,6 +751,22 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
     SWEEP_STAMP(0);
 #ifdef CSPM_SWEEP_TRACE
     if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + ((size_t)2 * pm.W * by0 + item) * kTraceSlots : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; for (int k = 8; k < kTraceSlots; ++k) s_tr[k] = 0; } }
+#ifndef CSPM_STEP_TRACE
+    {  // where the workgroup's waves sit: HW_ID (wave slot, SIMD, CU, SE) of every wave, 12 bits each, and the XCC in slot 15
+      __shared__ unsigned int s_hwid[kSweepMaxWaves];
+      unsigned int hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      if (lane == 0) s_hwid[wave] = hwid;
+      __syncthreads();
+      if (threadIdx.x == 0 && sw.trace) {
+        long long packed = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6) && k < 5; ++k) packed |= (long long)(s_hwid[k] & 0xFFFu) << (12 * k);
+        sw.trace[((size_t)2 * pm.W * by0 + item) * kTraceSlots + 14] = packed;
+        sw.trace[((size_t)2 * pm.W * by0 + item) * kTraceSlots + 15] = (long long)(((s_hwid[0] >> 13) & 7u) | ((xcc & 0xFu) << 4));
+      }
+    }
+#endif
 #endif
     while (k + 1 < ndiag && item >= bstart[k + 1]) ++k;  // items of one workgroup only increase
     const int ys_lo = max(by0, k - (pm.W - 1)), ys_hi = min(by1 - 1, k);
@@ -732,6 +780,8 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
     const long long jx = i - inc, jy = i - (long long)inc * pm.W;
     const bool have0 = xs > 0, have1 = ys > 0;
     SWEEP_STAMP(1);
+    // 0. everything of the evaluation that does not depend on the candidate planes, issued before the wait
+    const ChainLevel A = sweep_level_setup<CS, SRC>(cd, v, x, y, wave);
     // 1. wait for the predecessors' planes: lanes 0..23 of wave 0 poll one granule each; the data arrives with the tags
     if (wave == 0) {
       const int pred = lane >= kGranPerPixel ? 1 : 0, part = lane - pred * kGranPerPixel;
@@ -766,11 +816,11 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
       eval1 = have1 && !own1 && !(have0 && same01);
       SWEEP_STAMP(3);
       if (eval0 && eval1) {
-        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, true, wave, lane, cost0, cost1);
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, true, wave, lane, cost0, cost1, A);
       } else if (eval0) {
-        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c0, false, wave, lane, cost0, cost1);
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c0, false, wave, lane, cost0, cost1, A);
       } else if (eval1) {
-        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0);
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0, A);
       }
     }
     // 3. accept (x-predecessor first, then y-predecessor against the updated minimum; :198-212), publish the FINAL plane.
@@ -794,6 +844,200 @@ __global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_SWEEP_MINW) void k_spat
         if (lane == 6) f.cost[i] = best_cost;
       }
       SWEEP_STAMP(7);
+    }
+    __syncthreads();  // s_item / s_plane / scratch are reused by the next item
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same raster sweep, scheduled by DATAFLOW (round 5; an OPTION, CSPM_OPT_SWEEP_FLOW: built, bit-identical, measured SLOWER -- 27 ms per
+// sweep against 20: see the end of this comment).  What the trace of k_spatial_sweep showed (tools/sweep_trace.py,
+// profiles/r05_sweep_critical_path.txt): on the critical path through the dependency lattice a pixel costs 12.4 us, of which the
+// evaluation is 6.1, the hand-over of a plane 0.8 -- and 4.3-5.7 us are spent with the successor NOT YET CLAIMED when its last
+// predecessor publishes: workgroups claim pixels in a fixed diagonal-major order, so the successor that matters is picked up by
+// whichever workgroup happens to finish some other pixel, and workgroups that claimed early hold registers while they wait.
+// Here nobody claims ahead and nobody waits for a particular pixel: every pixel counts its final predecessors (`ready`), and the
+// workgroup whose pixel completes that count CONTINUES with the successor at once -- its own final plane stays in LDS, the other
+// predecessor's plane is already published (one load).  When both successors become ready it continues with one and pushes the other
+// to a queue that idle workgroups pop.  Every resident workgroup computes all the time; the order of evaluation differs, the
+// dependencies do not: every pixel still sees the FINAL planes of its two predecessors -- the reference's in-place raster order.
+// Deadlock freedom: a workgroup only ever blocks on an empty queue slot, holding nothing anybody needs; a ready pixel is either being
+// evaluated or in the queue.  Visibility: granules and queue entries are data-tagged with the sweep's epoch and read with agent-scope
+// loads, so a reader never trusts an ordering -- a tag that is not there yet just means another poll.  All spins are wall-clock bounded.
+// MEASURED (C3, profiles/r05_sweep_critical_path.txt): the late claims are gone (0.7 us per pixel of the critical path), a pixel takes
+// 9.0 us from start to publish -- and the sweep takes 26.9 ms instead of 20.0.  Without slack every delay propagates: the realised
+// critical path now runs through the TWO-candidate pixels (53 % of its pixels against 4 % of all pixels: they cost 10-11 us and line up
+// along the depth edges, which a monotone lattice path can follow), the ready counter's atomic adds 0.8 us to every pixel, and ready
+// pixels queue for a free workgroup all the same -- a CU evaluates two pixels at a time at full speed (above).  The ordered sweep hides
+// all of that behind its waiting workgroups.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flow_push(const Sweep &sw, unsigned int id) {
+  const unsigned int slot = __hip_atomic_fetch_add(&sw.qctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(sw.queue + slot, ((unsigned long long)sw.epoch << 32) | id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one thread: reserve the next queue slot and wait for its entry; -1 when the sweep is over (or failed)
+__device__ __forceinline__ int flow_pop(const Sweep &sw) {
+  if (__hip_atomic_load(&sw.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;  // an earlier sweep failed
+  const unsigned int slot = __hip_atomic_fetch_add(&sw.qctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+    const unsigned long long e = __hip_atomic_load(sw.queue + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned int)(e >> 32) == sw.epoch) return (int)(unsigned int)e;
+    __builtin_amdgcn_s_sleep(2);
+    if ((spins & 15u) == 0u) {
+      if (__hip_atomic_load(&sw.qctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 2u) return -1;  // both views are final
+      if (__hip_atomic_load(&sw.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
+      if (wall_clock64() - t0 > sw.timeout_ticks * 4) {  // nothing became ready for far longer than any evaluation takes
+        __hip_atomic_store(&sw.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+      }
+    }
+  }
+}
+#ifdef CSPM_SWEEP_TRACE
+#define FLOW_STAMP(slot) do { if (threadIdx.x == 0 && sw.trace) sw.trace[(size_t)item * kTraceSlots + (slot)] = wall_clock64(); } while (0)
+#else
+#define FLOW_STAMP(slot) do { } while (0)
+#endif
+
+// Residency (tools/ubench/residency.hip): five-wave workgroups leave one workgroup's worth of wave slots unused -- two are resident per CU
+// at 97-128 VGPRs, three at <= 96.  Measured with this kernel capped at 96 (CSPM_FLOW_MINW = 5): the compiler's code under that cap
+// evaluates a pixel in 9.3 us instead of 5.4 even on an empty GPU, and three workgroups that all COMPUTE oversubscribe the CU (23 us per
+// pixel, 52 ms per sweep).  So: the cap of the ordered sweep, two workgroups per CU.
+#ifndef CSPM_FLOW_MINW
+#define CSPM_FLOW_MINW CSPM_SWEEP_MINW
+#endif
+template <bool CS, int SRC>
+__global__ __launch_bounds__(kSweepMaxWaves *kWave, CSPM_FLOW_MINW) void k_spatial_flow(Cost cd, Pm pm, Sweep sw, int inc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const SweepShared sh = sweep_shared(smem);
+  __shared__ double s_plane[2][6];  // [0] the x-predecessor's final plane, [1] the y-predecessor's
+  __shared__ int s_item, s_from, s_ok;
+  const Luts lut = load_luts(cd, sh.lut);
+#if CSPM_SWEEP_PRIO
+  __builtin_amdgcn_s_setprio(CSPM_SWEEP_PRIO);
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const unsigned int npix = (unsigned int)pm.W * (unsigned int)pm.H;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the two pixels without predecessors
+    const unsigned int origin = inc > 0 ? 0u : npix - 1u;
+    flow_push(sw, origin);
+    flow_push(sw, npix + origin);
+  }
+  int next = -1, carry = -1;  // thread 0: the pixel this workgroup continues with, and which of its predecessors we are
+  for (;;) {
+    if (threadIdx.x == 0) {
+      int it = next, from = carry;
+      if (it < 0) { it = flow_pop(sw); from = -1; }
+      s_item = it;
+      s_from = from;
+      s_ok = 1;
+    }
+    __syncthreads();
+    const int item = s_item;
+    if (item < 0) return;
+    const int from = s_from;
+    FLOW_STAMP(0);
+#ifdef CSPM_SWEEP_TRACE
+    if (threadIdx.x == 0) { s_tr = sw.trace ? sw.trace + (size_t)item * kTraceSlots : nullptr; if (s_tr) { s_tr[4] = 0; s_tr[5] = 0; for (int k = 8; k < kTraceSlots; ++k) s_tr[k] = 0; s_tr[15] = from; } }
+#endif
+    const int v = (unsigned int)item >= npix ? 1 : 0;
+    const int pix = item - v * (int)npix;
+    const int y = pix / pm.W, x = pix - y * pm.W;
+    const int xs = inc > 0 ? x : pm.W - 1 - x, ys = inc > 0 ? y : pm.H - 1 - y;
+    const Field &f = pm.f[v];
+    const long long i = pix;
+    const long long jx = i - inc, jy = i - (long long)inc * pm.W;
+    const bool have0 = xs > 0, have1 = ys > 0;
+    FLOW_STAMP(1);
+    // 1. the predecessors' planes.  The one we continued from is in s_plane already; the other one is final (that is what made this
+    //    pixel ready) and published: lanes 0..23 of wave 0 load one granule each, issued BEFORE the level set-up so that it overlaps.
+    unsigned long long g = 0ull;
+    const int pred = lane >= kGranPerPixel ? 1 : 0, part = lane - pred * kGranPerPixel;
+    const bool need = wave == 0 && lane < 2 * kGranPerPixel && (pred == 0 ? have0 : have1) && pred != from;
+    const unsigned long long *gp = sw.gran[v] + (pred == 0 ? jx : jy) * kGranPerPixel + (need ? part : 0);
+    if (need) g = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // 0. everything of the evaluation that does not depend on the candidate planes
+    const ChainLevel A = sweep_level_setup<CS, SRC>(cd, v, x, y, wave);
+    if (wave == 0) {
+      bool ok = true;
+      if (__builtin_amdgcn_ballot_w64(need && (unsigned int)(g >> 32) != sw.epoch) != 0ull)  // not visible yet: poll (rare)
+        ok = wait_granules(gp, need, sw.epoch, &sw.ctrl[1], sw.timeout_ticks, g);
+      if (need) reinterpret_cast<uint32_t *>(&s_plane[0][0])[lane] = (uint32_t)g;  // s_plane[pred][part / 2], half part % 2
+      if (lane == 0 && !ok) s_ok = 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    FLOW_STAMP(2);
+    // 2. both candidate costs in one pass over the window (as k_spatial_sweep)
+    double cost0 = 0.0, cost1 = 0.0;
+    bool eval0 = false, eval1 = false;
+    if (have0 || have1) {
+      const int p0 = have0 ? 0 : 1, p1 = have1 ? 1 : 0;
+      const Cand c0{s_plane[p0][0], s_plane[p0][1], s_plane[p0][2], s_plane[p0][3], s_plane[p0][4], s_plane[p0][5]};
+      const Cand c1{s_plane[p1][0], s_plane[p1][1], s_plane[p1][2], s_plane[p1][3], s_plane[p1][4], s_plane[p1][5]};
+      const Cand own{f.nx[i], f.ny[i], f.nz[i], f.a[i], f.b[i], f.c[i]};
+      const bool same01 = c0.nx == c1.nx && c0.ny == c1.ny && c0.nz == c1.nz && c0.a == c1.a && c0.b == c1.b && c0.c == c1.c;
+      const bool trust = pm.trust_cost != 0;
+      const bool own0 = trust && c0.nx == own.nx && c0.ny == own.ny && c0.nz == own.nz && c0.a == own.a && c0.b == own.b && c0.c == own.c;
+      const bool own1 = trust && c1.nx == own.nx && c1.ny == own.ny && c1.nz == own.nz && c1.a == own.a && c1.b == own.b && c1.c == own.c;
+      eval0 = have0 && !own0;
+      eval1 = have1 && !own1 && !(have0 && same01);
+      FLOW_STAMP(3);
+      if (eval0 && eval1) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c1, true, wave, lane, cost0, cost1, A);
+      } else if (eval0) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c0, c0, false, wave, lane, cost0, cost1, A);
+      } else if (eval1) {
+        eval_pixel_pair<CS, SRC>(cd, lut, sh, v, x, y, c1, c1, false, wave, lane, cost1, cost0, A);
+      } else {
+        __syncthreads();  // every wave has read s_plane before wave 0 overwrites it below
+      }
+    } else {
+      FLOW_STAMP(3);
+      __syncthreads();
+    }
+    // 3. accept (x-predecessor first, then y-predecessor against the updated minimum; :198-212), publish the FINAL plane, count it at
+    //    the successors and decide what this workgroup does next.
+    if (wave == 0) {
+      double best_cost = f.cost[i];
+      int pick = -1;
+      if (eval0 && cost0 < best_cost) { best_cost = cost0; pick = 0; }
+      if (eval1 && cost1 < best_cost) { best_cost = cost1; pick = 1; }
+      FLOW_STAMP(6);
+      const long long comp = f.ny - f.nx;  // the six components of a view's plane field are equally spaced arrays
+      double fin = 0.0;  // lanes 0..11: component lane >> 1 of the final plane
+      if (lane < kGranPerPixel) {
+        const int k = lane >> 1;
+        fin = pick >= 0 ? s_plane[pick][k] : f.nx[k * comp + i];
+        const unsigned int half = (lane & 1) ? (unsigned int)__double2hiint(fin) : (unsigned int)__double2loint(fin);
+        __hip_atomic_store(sw.gran[v] + (size_t)i * kGranPerPixel + lane, ((unsigned long long)sw.epoch << 32) | half, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (pick >= 0) {  // the plane field, for the kernels after the sweep
+        if (lane < 6) f.nx[lane * comp + i] = s_plane[pick][lane];
+        if (lane == 6) f.cost[i] = best_cost;
+      }
+      // (no wait for the granule stores: a successor that finds a stale tag polls -- the tags, not an ordering, make the data valid)
+      // successors: lane 0 the next pixel of the row (this pixel is its x-predecessor), lane 1 the one below (its y-predecessor)
+      const bool ex = lane == 0 ? xs + 1 < pm.W : (lane == 1 ? ys + 1 < pm.H : false);
+      const long long si = lane == 0 ? i + inc : i + (long long)inc * pm.W;
+      const unsigned int want = lane == 0 ? (ys > 0 ? 2u : 1u) : (xs > 0 ? 2u : 1u);
+      bool rdy = false;
+      if (ex) rdy = __hip_atomic_fetch_add(sw.ready[v] + si, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == want;
+      const unsigned long long rb = __builtin_amdgcn_ballot_w64(rdy);
+      const bool r0 = (rb & 1ull) != 0ull, r1 = (rb & 2ull) != 0ull;
+      const int cont = r0 ? 0 : (r1 ? 1 : -1);  // continue along the row when that pixel is ready, else downwards
+      if (lane == 1 && r0 && r1) flow_push(sw, (unsigned int)(v * (int)npix) + (unsigned int)si);
+      if (lane == 0) {
+        next = cont < 0 ? -1 : v * (int)npix + (int)(cont == 0 ? i + inc : i + (long long)inc * pm.W);
+        carry = cont;
+        if (xs + 1 == pm.W && ys + 1 == pm.H) __hip_atomic_fetch_add(&sw.qctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // this view is final
+      }
+      // our final plane becomes predecessor `cont` of the pixel we continue with (nobody else reads s_plane any more)
+      if (cont >= 0 && lane < kGranPerPixel && (lane & 1) == 0) s_plane[cont][lane >> 1] = fin;
+      FLOW_STAMP(7);
     }
     __syncthreads();  // s_item / s_plane / scratch are reused by the next item
   }

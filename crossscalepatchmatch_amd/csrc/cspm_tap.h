@@ -197,11 +197,31 @@ __device__ __forceinline__ double img_cell(uint32_t Iq, double Gq, uint32_t If, 
   return 0.1 * __builtin_fmin(clr, 10.0) + (1 - 0.1) * __builtin_fmin(grd, 2.0);
 }
 
-// balanced binary tree over the 64 lanes (neighbours first): every lane ends with the same bits because a+b == b+a
+// balanced binary tree over the 64 lanes (neighbours first): every lane ends with the same bits because a+b == b+a.
+// Round 5: the exchanges are DPP moves and v_readlane instead of six dependent rounds of ds_bpermute (each an LDS-pipe round trip; the
+// tree closes every level of every sweep pixel, 1.4 us of a 10 us pixel).  Level g of the tree adds, in every lane, the sum of the lane's
+// group of 2^g lanes and the sum of the neighbouring group; after level g all lanes of a group hold the same value, so ANY lane of the
+// neighbouring group is a valid source: xor 1 and xor 2 are quad permutes, the 4-lane groups meet by row_half_mirror (i <-> 7-i), the
+// 8-lane groups by row_mirror (i <-> 15-i), and the four 16-lane rows are read out with v_readlane: (r0+r1) + (r2+r3) is what the lanes
+// of rows 0-1 computed with __shfl_xor, (r2+r3) + (r0+r1) what rows 2-3 did -- the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_tree_sum(double v) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
-  return v;
+  v = v + dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v = v + dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v = v + dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v = v + dpp_f64<0x140>(v);  // row_mirror: the other half of the 16
+  const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+  const double a = r0 + r1, b = r2 + r3;
+  return a + b;
 }
 
 // LDS copies of the two lookup tables, one per workgroup

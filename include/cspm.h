@@ -118,13 +118,21 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
 #define CSPM_OPT_TABLE_VOLUMES 7
 #define CSPM_OPT_TABLE_VOLUMES_ACTIVE 8
 #define CSPM_OPT_VOLUME_FALLBACKS 9
-/* CSPM_OPT_SWEEP_PACKED (set before cspm_build_cost_grd; GRD with fused cells only; default 1): the raster sweep (SpatialPropagation,
+/* CSPM_OPT_SWEEP_PACKED (set before cspm_build_cost_grd; GRD with fused cells only; default 0): 1 = the raster sweep (SpatialPropagation,
  * whose window taps are gathers) reads the level images as PACKED 8-byte pixels {36-bit fixed-point x-gradient, 24-bit colour} --
  * lossless: the gradient of an 8-bit image's f32 gray values (grd_cc.cpp:70-77) is a multiple of 2^-27 below 256 -- so that a tap's two
  * adjacent other-view pixels arrive with one 16-byte gather and its own pixel with one 8-byte gather (2 gathers / 24 B instead of
  * 3 / 36 B per tap through the CU's L1).  Same cells, same order: identical planes.  0 = the 12-byte pixels every other kernel reads.
+ * Measured on MI355X: 8 % SLOWER (65.3 against 60.5 ms of sweeps per KITTI-size pair) although the microbenchmark confirms the L1 path
+ * does a third less work -- the sweep is bound by the latency of its dependent steps, and unpacking adds instructions to each: off.
  * CSPM_OPT_SWEEP_PACKED_ACTIVE (read only): 1 when the current cost object carries the packed pixels.
  * CSPM_OPT_SWEEP_PACKED_BAD (read only; synchronises): pixels the packer could not represent exactly -- 0 by construction. */
+/* CSPM_OPT_SWEEP_FLOW (default 0; measured on MI355X: 1 is 35 % slower, 26.9 against 20.0 ms per sweep of a KITTI-size pair): how the
+ * persistent raster sweep (CSPM_OPT_RASTER_LAUNCHES = 0) hands out its pixels.  1 = by dataflow:
+ * every pixel counts its final predecessors and the workgroup that completes the count continues with it at once (the other ready
+ * successor goes to a queue idle workgroups pop); 0 = workgroups claim pixels in diagonal-major order and wait for their predecessors.
+ * The dependencies, hence the planes, are the same: the reference's in-place raster order (cs_patchmatch.cc:163-216). */
+#define CSPM_OPT_SWEEP_FLOW 13
 #define CSPM_OPT_SWEEP_PACKED 10
 #define CSPM_OPT_SWEEP_PACKED_ACTIVE 11
 #define CSPM_OPT_SWEEP_PACKED_BAD 12

@@ -157,8 +157,8 @@ def test_adversarial_plane_cost_batch(gpu_ctx):
 
 @pytest.mark.parametrize("kind", ["saturated", "stripes", "identical", "white", "noise"])
 def test_sweep_packed_pixels_equal_the_12_byte_pixels(gpu_ctx, kind):
-    """The raster sweep reads packed 8-byte pixels {36-bit fixed-point gradient, colour} (CSPM_OPT_SWEEP_PACKED, the default); every
-    other kernel and cspm_plane_cost_batch read the 12-byte pixels {f64 gradient, colour}.  Lossless by construction: no pixel may
+    """With CSPM_OPT_SWEEP_PACKED the raster sweep reads packed 8-byte pixels {36-bit fixed-point gradient, colour} (an option: measured
+    slower, off by default); every other kernel and cspm_plane_cost_batch read the 12-byte pixels {f64 gradient, colour}.  Lossless by construction: no pixel may
     be reported unrepresentable, and the sweep must give the same planes and costs either way -- on the inputs with the largest
     gradients (0/255 stripes and blocks), on noise, cross-scale and single scale, persistent and per-diagonal sweeps."""
     from crossscalepatchmatch_amd import capi
@@ -179,7 +179,7 @@ def test_sweep_packed_pixels_equal_the_12_byte_pixels(gpu_ctx, kind):
                 gpu_ctx.patchmatch(2, seed=6, schedule=po.SCHED_RASTER)
                 out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
             finally:
-                gpu_ctx.set_option(capi.OPT_SWEEP_PACKED, 1)
+                gpu_ctx.set_option(capi.OPT_SWEEP_PACKED, 0)
                 gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
         for k in (1, 2):
             for v in (0, 1):
@@ -192,3 +192,56 @@ def test_sweep_packed_pixels_equal_the_12_byte_pixels(gpu_ctx, kind):
         for v in (0, 1):
             npar, cost = out[0][v]
             np.testing.assert_array_equal(gpu_ctx.plane_cost_batch(v, np.stack([xs, ys], 1), npar[ys, xs]), cost[ys, xs])
+
+
+@pytest.mark.parametrize("kind", ["blocks", "black", "noise", "tall"])
+def test_sweep_dataflow_scheduling_equals_ordered_claims(gpu_ctx, kind):
+    """The persistent raster sweep hands out its pixels by ordered claims (the default) or by dataflow (CSPM_OPT_SWEEP_FLOW = 1: the
+    workgroup that makes a pixel ready continues with it; an option, measured slower); the per-diagonal launches are the third schedule.  The dependencies are
+    the reference's raster order in all three: identical planes and costs -- on tie-heavy pairs (where the order of evaluation would
+    show if it leaked into a decision), on noise, on a tall narrow pair (long columns: continuation mostly downwards), single- and
+    cross-scale, with 1 and 3 workgroups per CU."""
+    import os
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import capi
+    if kind == "noise":
+        l, r = synth.make_pair(W, H, D, regions=3, seed=12)[:2]
+    elif kind == "tall":
+        l, r = synth.make_pair(40, 200, 12, regions=3, seed=13)[:2]
+    else:
+        l, r = synth.make_adversarial(kind, W, H, D, seed=14)
+    max_dis = 12 if kind == "tall" else D
+    for sn, lam in ((5, 0.3), (0, 0.0)):
+        out = []
+        for flow, launches in ((1, 0), (0, 0), (0, 1)):
+            try:
+                gpu_ctx.set_option(capi.OPT_SWEEP_FLOW, flow)
+                gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, launches)
+                gpu_ctx.set_images(l, r)
+                gpu_ctx.build_cost_grd(max_dis, 35, sn, lam)
+                gpu_ctx.patchmatch(3, seed=6, schedule=po.SCHED_RASTER)
+                out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+                assert gpu_ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 0
+            finally:
+                gpu_ctx.set_option(capi.OPT_SWEEP_FLOW, 0)
+                gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
+        for wg in (1, 3):
+            os.environ["CSPM_SWEEP_WG"] = str(wg)
+            os.environ["CSPM_SWEEP_FLOW"] = "1"
+            try:
+                ctx = cs.StereoContext(0)
+            finally:
+                del os.environ["CSPM_SWEEP_WG"]
+                del os.environ["CSPM_SWEEP_FLOW"]
+            try:
+                ctx.set_images(l, r)
+                ctx.build_cost_grd(max_dis, 35, sn, lam)
+                ctx.patchmatch(3, seed=6, schedule=po.SCHED_RASTER)
+                out.append([ctx.get_planes(v) for v in (0, 1)])
+                assert ctx.get_option(capi.OPT_SWEEP_FALLBACKS) == 0
+            finally:
+                ctx.close()
+        for k in range(1, len(out)):
+            for v in (0, 1):
+                np.testing.assert_array_equal(out[0][v][0], out[k][v][0], err_msg=f"{kind} scale_num {sn} variant {k} view {v}")
+                np.testing.assert_array_equal(out[0][v][1], out[k][v][1], err_msg=f"{kind} scale_num {sn} variant {k} view {v}")
