@@ -26,6 +26,7 @@ OPT_SWEEP_PACKED = 10        # packed 8-byte pixels for the raster sweep (defaul
 OPT_SWEEP_PACKED_ACTIVE = 11 # read only
 OPT_SWEEP_PACKED_BAD = 12    # read only, synchronises: pixels the packer could not represent (0 by construction)
 OPT_SWEEP_FLOW = 13          # persistent raster sweep scheduled by dataflow (1: measured slower) or by ordered claims (0, default)
+OPT_SWEEP_WG = 14            # persistent sweep workgroups per CU (0 = default 2; 1 when three or more pairs are in flight on the GPU)
 OPT_VOLUME_FALLBACKS = 9     # read only: hipMalloc failures of an optional volume this context survived
 
 # every symbol include/cspm.h declares

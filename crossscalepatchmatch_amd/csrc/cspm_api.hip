@@ -1135,6 +1135,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_TABLE_VOLUMES: c->opt_table_volumes = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: c->opt_sweep_packed = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: c->opt_sweep_flow = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_WG: c->sweep_wg_per_cu = value < 0 ? 0 : (value > 16 ? 16 : (int)value); return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -1157,6 +1158,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: *value = c->opt_sweep_flow; return CSPM_OK;
+    case CSPM_OPT_SWEEP_WG: *value = c->sweep_wg_per_cu; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED_ACTIVE: *value = c->sweep_packed ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED_BAD: {  // synchronises: gradients the packer could not represent (always 0 for 8-bit images)
       if (!c->cost_alloc || !c->d_px8_bad) { *value = 0; return CSPM_OK; }
@@ -1722,6 +1724,12 @@ int cspm_debug_alive(unsigned long long *out16, int reset) {
   unsigned long long z[16] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(cspm::g_alive), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
   if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_alive), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  return CSPM_OK;
+}
+int cspm_debug_alive_hist(unsigned long long *out120, int reset) {  // [3 groups][8 levels][5 buckets]
+  static unsigned long long z[120];
+  if (hipMemcpyFromSymbol(out120, HIP_SYMBOL(cspm::g_alive_hist), sizeof z) != hipSuccess) return CSPM_ERR_HIP;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(cspm::g_alive_hist), z, sizeof z) != hipSuccess) return CSPM_ERR_HIP;
   return CSPM_OK;
 }
 #endif

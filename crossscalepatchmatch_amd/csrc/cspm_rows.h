@@ -576,6 +576,9 @@ struct RowCtx {
 #ifdef CSPM_ROW_STATS
   int stat_slot;
 #endif
+#ifdef CSPM_COUNT_ALIVE
+  int tag;           // histogram group: 0 = refinement steps 0-3, 1 = refinement steps >= 4, 2 = everything else
+#endif
   int y;             // all lanes evaluate in row y
   int lane;
   char *strip;       // this wave's other-view strip, `cap` slots of 16 bytes
@@ -588,6 +591,9 @@ __device__ __forceinline__ RowCtx make_row_ctx(unsigned char *smem, int y, int c
   return RowCtx{
 #ifdef CSPM_ROW_STATS
       0,
+#endif
+#ifdef CSPM_COUNT_ALIVE
+      2,
 #endif
       y, (int)(threadIdx.x & 63), base, base + (size_t)cap * 16, cap, ocap};
 }
@@ -1203,6 +1209,9 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
 
 #ifdef CSPM_COUNT_ALIVE
 __device__ unsigned long long g_alive[16];  // debug: lanes still alive after level s, lanes evaluated at level s
+// debug: level passes by the number of lanes that still carry a live candidate when the pass STARTS: [group][level][bucket], buckets
+// 1-8, 9-16, 17-32, 33-48, 49-64 live lanes (a wave with no live lane never starts the pass)
+__device__ unsigned long long g_alive_hist[3][8][5];
 #endif
 
 // A candidate plane as a lane holds it between uses: Plane::norm() and Plane::param()
@@ -1226,6 +1235,13 @@ __device__ __forceinline__ double eval_rows_view(const Cost &cd, const Luts &lut
   bool dead = false;
   const int levels = CS ? cd.levels : 1;
   for (int s = 0; s < levels; ++s) {
+#ifdef CSPM_COUNT_ALIVE
+    if (use_thresh) {
+      const int n_live = __popcll(__builtin_amdgcn_ballot_w64(!dead));
+      const int bucket = n_live <= 8 ? 0 : n_live <= 16 ? 1 : n_live <= 32 ? 2 : n_live <= 48 ? 3 : 4;
+      if (ctx.lane == 0) atomicAdd(&g_alive_hist[ctx.tag][s][bucket], 1ull);
+    }
+#endif
     int xs = x;
     asm volatile("" : "+v"(xs));
     const RowPlane p = gen(xs);
@@ -1434,6 +1450,9 @@ __global__ __launch_bounds__(kRowBlock, CSPM_ROW_MINW) void k_refine(Cost cd, Pm
   for (int step = first_step; step < first_step + nsteps; ++step) {
 #ifdef CSPM_ROW_STATS
     ctx.stat_slot = 2 + step;
+#endif
+#ifdef CSPM_COUNT_ALIVE
+    ctx.tag = step < 4 ? 0 : 1;
 #endif
     auto gen = [&](int xs) { return refine_plane(pm, it.v, xs, it.y, iter, step, z_iter, n_iter); };
     const double cost = eval_rows<CS, SRC>(cd, lut, ctx, it.v, x, gen, cur_min, use_thresh);

@@ -133,6 +133,11 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * successor goes to a queue idle workgroups pop); 0 = workgroups claim pixels in diagonal-major order and wait for their predecessors.
  * The dependencies, hence the planes, are the same: the reference's in-place raster order (cs_patchmatch.cc:163-216). */
 #define CSPM_OPT_SWEEP_FLOW 13
+/* CSPM_OPT_SWEEP_WG (default 0 = 2): workgroups of the persistent raster sweep launched per CU.  A pair that has the GPU to itself wants 2
+ * (one: 87 instead of 59 ms of sweeps per KITTI-size pair; more are not resident).  A caller that keeps THREE OR MORE pairs in flight on one
+ * GPU (contexts on separate streams) should set 1: the sweep's workgroups hold registers and LDS that the other pairs' throughput kernels
+ * would use -- measured with 3 pairs in flight: 146.5 ms per pair with 1, 150.6 with 2, 152.1 with 3. */
+#define CSPM_OPT_SWEEP_WG 14
 #define CSPM_OPT_SWEEP_PACKED 10
 #define CSPM_OPT_SWEEP_PACKED_ACTIVE 11
 #define CSPM_OPT_SWEEP_PACKED_BAD 12
