@@ -13,6 +13,7 @@
 // After the passes the chain sums go through LDS once: lane dy adds the 7 partial sums of row dy, and an xor butterfly
 // over the lanes forms the row tree.
 #pragma once
+#include <type_traits>
 #include "cspm_tap.h"
 
 #pragma clang fp contract(off)
@@ -114,6 +115,9 @@ __device__ __forceinline__ unsigned long long step_stamp(unsigned dep0, unsigned
 // run the pipelined one, which keeps it compiled and tested: two schedules of the same arithmetic that must agree bit for bit.
 #ifndef CSPM_SWEEP_PIPE
 #define CSPM_SWEEP_PIPE 0
+#endif
+#ifndef CSPM_CHAIN_ALLV
+#define CSPM_CHAIN_ALLV 1
 #endif
 
 // a value that is the same in every lane of the wave (the candidate planes of a pixel, the window centre's colour): telling the compiler
@@ -263,6 +267,32 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
     return;
   }
 #endif
+  // All-valid levels (round 5): the disparity of a tap is linear in its column and row, so when it lies in [1 + 2^-20, D - 2^-20] at the
+  // four corners of the window -- for every candidate -- every tap of the level takes the interpolation branch of pre_cs_pc.cc:166-175:
+  // that level runs without clamp, validity test and select (4 of ~29 instructions per tap and candidate; the margin covers the roundings
+  // of the device-order disparity against the corner values, as in the row engine's all-valid rows).  True for most pixels of a sweep:
+  // its candidates are the neighbours' settled planes.  Same arithmetic for the taps that were valid anyway: identical bits.
+  bool allv = (SRC == kSrcGrd || SRC == kSrcCen || SRC == kSrcGrd8 || SRC == kSrcVolume || SRC == kSrcVol2) && A.has_valid;
+#if defined(CSPM_STEP_TRACE) || !CSPM_CHAIN_ALLV
+  allv = false;
+#endif
+  if (allv) {
+    const double x0 = (double)A.ox0, x1 = (double)(A.ox0 + kRowMod * A.nsteps - 1);  // the last step's masked taps beyond the window form addresses too
+    const double y0 = (double)(A.oy0 + A.r_lo), y1 = (double)(A.oy0 + A.r_lo + A.nrows - 1);
+    const double lo = 1.0 + 0x1p-20, hi = (double)(A.Dm1 + 1) - 0x1p-20;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double t0 = pl[c].b * y0 + pl[c].c, t1 = pl[c].b * y1 + pl[c].c;
+      const double q00 = __builtin_fma(pl[c].a, x0, t0), q01 = __builtin_fma(pl[c].a, x1, t0);
+      const double q10 = __builtin_fma(pl[c].a, x0, t1), q11 = __builtin_fma(pl[c].a, x1, t1);
+      const double qmin = __builtin_fmin(__builtin_fmin(q00, q01), __builtin_fmin(q10, q11));
+      const double qmax = __builtin_fmax(__builtin_fmax(q00, q01), __builtin_fmax(q10, q11));
+      allv = allv & (qmin >= lo) & (qmax <= hi);  // false for NaN
+    }
+    allv = __builtin_amdgcn_ballot_w64(!allv) == 0ull;  // the planes are wave-uniform; this makes the branch below a scalar one
+  }
+  auto run_passes = [&](auto allv_tag) {
+  constexpr bool ALLV = decltype(allv_tag)::value;
   for (int p = pass_first; p < A.passes; p += pass_step) {
     double acc[NC];
 #pragma unroll
@@ -312,7 +342,7 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           acc[c] = __builtin_fma(wgt, g.valid ? cell : A.maxc, acc[c]);
           continue;
         }
-        const DispSplit d = split_disp(q_disp, A.Dm1, A.has_valid);
+        const DispSplit d = ALLV ? split_disp_valid(q_disp) : split_disp(q_disp, A.Dm1, A.has_valid);
         double c0, c1;
         if constexpr (SRC == kSrcVol2) {
           // one 16-byte gather: {cell(f), cell(f+1)} of this tap's pixel.  Masked taps (weight 0) read the window centre's column.
@@ -350,7 +380,7 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of + A.dirE));
 #endif
         }
-        acc[c] = __builtin_fma(wgt, tap_value(d, c0, c1, A.maxc), acc[c]);  // :176-177
+        acc[c] = __builtin_fma(wgt, ALLV ? lerp_cells(d.fr, c0, c1) : tap_value(d, c0, c1, A.maxc), acc[c]);  // :176-177
       }
 #if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
       STEP_STAMP(5, __double2hiint(acc[0]), __double2hiint(acc[NC - 1]));  // the step's accumulations
@@ -365,6 +395,9 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
 #pragma unroll
     for (int c = 0; c < NC; ++c) part[c][p * kWave + lane] = acc[c];
   }
+  };
+  if (allv) run_passes(std::true_type{});
+  else run_passes(std::false_type{});
 }
 
 // chain sums of ONE candidate (already stored pass-major in part[]) -> level sum, identical in all lanes:

@@ -627,12 +627,7 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
     px = reinterpret_cast<const char *>(L.px[VIEW]); opx = reinterpret_cast<const char *>(L.px[1 - VIEW]);
   }
   // the wave's span of centres: decides the strip windows and whether any lane needs the column mask
-  int cmin = cx, cmax = cx;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    cmin = min(cmin, __shfl_xor(cmin, off, kWave));
-    cmax = max(cmax, __shfl_xor(cmax, off, kWave));
-  }
+  int cmin = wave_min_i32(cx), cmax = wave_max_i32(cx);
   cmin = __builtin_amdgcn_readfirstlane(cmin);
   cmax = __builtin_amdgcn_readfirstlane(cmax);
   const bool edge = (cmin - A.half < 0) | (cmax + A.half >= A.W);
@@ -721,13 +716,8 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         const bool safe = (qmin >= 1.0 + 0x1p-20) & (qmax <= (double)D - 0x1p-20);  // false for NaN
         f_lo = fl_lane = safe ? (int)(qmin - 0x1p-20) : 1;
         f_hi = fh_lane = safe ? min((int)(qmax + 0x1p-20) + 1, D) : 1;  // qmax == D - 2^-20 exactly would name slab D + 1: no tap reads beyond slab D
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-          f_lo = min(f_lo, __shfl_xor(f_lo, off, kWave));
-          f_hi = max(f_hi, __shfl_xor(f_hi, off, kWave));
-        }
-        f_lo = __builtin_amdgcn_readfirstlane(f_lo);
-        f_hi = __builtin_amdgcn_readfirstlane(f_hi);
+        f_lo = wave_min_i32(f_lo);
+        f_hi = wave_max_i32(f_hi);
         range_ok = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
       }
       const int nd = f_hi - f_lo + 1;
@@ -767,13 +757,8 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
           const bool in_a = fh_lane < cut, in_b = fl_lane >= cut;
           if (__builtin_amdgcn_ballot_w64(!(in_a | in_b)) == 0ull) {
             int a_hi = in_a ? fh_lane : f_lo, bl = in_b ? fl_lane : f_hi;
-#pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-              a_hi = max(a_hi, __shfl_xor(a_hi, off, kWave));
-              bl = min(bl, __shfl_xor(bl, off, kWave));
-            }
-            a_hi = __builtin_amdgcn_readfirstlane(a_hi);
-            bl = __builtin_amdgcn_readfirstlane(bl);
+            a_hi = wave_max_i32(a_hi);
+            bl = wave_min_i32(bl);
             const int na = a_hi - f_lo + 1, nb_ = f_hi - bl + 1, nt = na + nb_;
             const bool span_ok = span32(f_hi - f_lo + 1);  // 32-bit DMA offsets: cluster B's rows are addressed from cluster A's first slab
             if (nt < nd && span_ok) {

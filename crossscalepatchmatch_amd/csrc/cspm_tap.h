@@ -224,6 +224,26 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
   return a + b;
 }
 
+// wave-wide integer min / max, the result in every lane (wave-uniform, in a scalar register): DPP exchanges within the 16-lane rows,
+// v_readlane across them -- instead of six dependent ds_bpermute round trips (the row engine reduces its lanes' disparity intervals
+// several times per level pass)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, dpp_i32<0xB1>(v));
+  v = min(v, dpp_i32<0x4E>(v));
+  v = min(v, dpp_i32<0x141>(v));
+  v = min(v, dpp_i32<0x140>(v));
+  return __builtin_amdgcn_readfirstlane(min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48))));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, dpp_i32<0xB1>(v));
+  v = max(v, dpp_i32<0x4E>(v));
+  v = max(v, dpp_i32<0x141>(v));
+  v = max(v, dpp_i32<0x140>(v));
+  return __builtin_amdgcn_readfirstlane(max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48))));
+}
+
 // LDS copies of the two lookup tables, one per workgroup
 struct LutMem {
   double w[kLutSize];
