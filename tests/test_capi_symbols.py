@@ -118,3 +118,19 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     rc, msg = out.stdout.strip().split("|", 1)
     assert int(rc) < 0 and msg  # a negative status and a message
+
+
+def test_python_constants_mirror_the_header():
+    """capi.py repeats the option keys, kernel classes and phase codes of include/cspm.h by hand: they must not drift apart."""
+    import re
+    from crossscalepatchmatch_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "cspm.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+(CSPM_[A-Z0-9_]+)\s+(-?\d+)\s*(?:/\*.*)?$", hdr, re.M)}
+    opts = {k: v for k, v in defs.items() if k.startswith("CSPM_OPT_")}
+    assert len(set(opts.values())) == len(opts), "two options share a key"
+    for name, value in opts.items():
+        py = name[len("CSPM_"):]
+        assert getattr(capi, py) == value, name
+    for k, name in enumerate(capi.K_NAMES):
+        assert defs["CSPM_K_" + {"grd": "GRD", "init": "INIT", "spatial": "SPATIAL", "view": "VIEW", "refine": "REFINE", "misc": "MISC", "post": "POST"}[name]] == k
+    assert defs["CSPM_K_COUNT"] == len(capi.K_NAMES)
