@@ -12,8 +12,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from crossscalepatchmatch_amd import capi, synth  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
 
-index = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-cfg, l, r, gl, gr = synth.make_config("C3", index=index)
+# argument: a pair index (synthetic KITTI-size pair, seed 2000 + index) or the name of an adversarial kind of synth.make_adversarial at
+# the C3 size (tie-heavy / saturated / flat inputs through the DMA-filled tables, range tests and clusters of the full-size row kernels)
+arg = sys.argv[1] if len(sys.argv) > 1 else "0"
+if arg in synth.ADVERSARIAL_KINDS:
+    cfg = dict(synth.CONFIGS["C3"])
+    l, r = synth.make_adversarial(arg, cfg["w"], cfg["h"], cfg["max_dis"], seed=77)
+    index = arg
+else:
+    index = int(arg)
+    cfg, l, r, gl, gr = synth.make_config("C3", index=index)
 seed = 12345
 ctx = capi.StereoContext(0)
 ctx.set_images(l, r)
@@ -23,11 +31,11 @@ ctx.patchmatch(3, seed=seed, schedule=0)
 got = [ctx.get_planes(v) for v in (0, 1)]
 maps = [ctx.disparity_u8(v, cfg["dis_scale"]) for v in (0, 1)]
 t_gpu = time.time() - t
-print(f"C3 pair index {index} (synthetic seed 2000+{index}), PatchMatch seed {seed}: GPU {t_gpu:.2f} s host to host", flush=True)
+print(f"C3 pair {index} ({'adversarial kind' if isinstance(index, str) else 'synthetic seed 2000+' + str(index)}), PatchMatch seed {seed}: GPU {t_gpu:.2f} s host to host", flush=True)
 t = time.time()
 pc = po.PlaneCost(l, r, cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
 pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
-pm.run(3, pc, False, seed=seed, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+pm.run(3, pc, False, seed=seed, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE, wavefront=True)  # the oracle's sweep as a wavefront: identical to its serial loop (tests/test_oracle_primitives.py)
 t_cpu = time.time() - t
 print(f"oracle, device order, {po.effective_cpus()} threads: {t_cpu:.1f} s", flush=True)
 ok = True
