@@ -9,6 +9,7 @@
 // construction after refcheck::begin() identifies (phase, iteration, halving step, view) and the n-th uniform() of a row its pixel.
 #pragma once
 #include <algorithm>
+#include <bitset>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -33,7 +34,7 @@ namespace cv {
 
 typedef unsigned char uchar;
 enum { CV_8U = 0, CV_32F = 5, CV_64F = 6 };
-enum { CV_BGR2RGB = 4, CV_RGB2GRAY = 7 };
+enum { CV_BGR2RGB = 4, CV_BGR2GRAY = 6, CV_RGB2GRAY = 7, CV_BGR2Lab = 44 };
 enum { NORM_L2 = 4 };
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << 3))
 #define CV_8UC1 CV_MAKETYPE(cv::CV_8U, 1)
@@ -90,7 +91,10 @@ class Mat {
       else v = reinterpret_cast<const double *>(data)[i];
       if (rdepth == CV_64F) reinterpret_cast<double *>(out.data)[i] = v;
       else if (rdepth == CV_32F) reinterpret_cast<float *>(out.data)[i] = (float)v;
-      else throw std::runtime_error("refcheck stand-in: convertTo to 8U is not used by the path");
+      else {  // saturate_cast<uchar>(double): round half to even, clamp (cen_cc.cc:13: the values are the integers of an 8-bit image)
+        const double rv = std::nearbyint(v);
+        out.data[i] = (uchar)(rv < 0 ? 0 : rv > 255 ? 255 : rv);
+      }
     }
     dst = out;
   }
@@ -207,7 +211,7 @@ inline void cvtColor(const Mat &src, Mat &dst, int code) {
     Mat out(src.rows, src.cols, CV_8UC3);
     for (int i = 0; i < src.rows * src.cols; ++i) { out.data[3 * i] = src.data[3 * i + 2]; out.data[3 * i + 1] = src.data[3 * i + 1]; out.data[3 * i + 2] = src.data[3 * i]; }
     dst = out;
-  } else if (code == CV_RGB2GRAY) {  // on 32F: r*0.299f + g*0.587f + b*0.114f in float, the oracle's contract
+  } else if (code == CV_RGB2GRAY && src.depth() == CV_32F) {  // on 32F: r*0.299f + g*0.587f + b*0.114f in float, the oracle's contract
     CV_Assert(src.type() == CV_32FC3);
     const int n = src.rows * src.cols;
     std::vector<double> rgb((size_t)n * 3);
@@ -215,14 +219,37 @@ inline void cvtColor(const Mat &src, Mat &dst, int code) {
     Mat out(src.rows, src.cols, CV_32FC1);
     csor_rgb2gray_f32(rgb.data(), src.cols, src.rows, reinterpret_cast<float *>(out.data));
     dst = out;
+  } else if (code == CV_RGB2GRAY || code == CV_BGR2GRAY) {
+    // on 8UC3: OpenCV 2.4's fixed-point weights R 4899, G 9617, B 1868, >> 14 with rounding (the contract the oracle restates for
+    // CenCC, cen_cc.cc:14, and for GrdPC / CSPC, grd_pc.cc:37)
+    CV_Assert(src.type() == CV_8UC3);
+    Mat out(src.rows, src.cols, CV_8UC1);
+    const int ri = code == CV_RGB2GRAY ? 0 : 2, bi = 2 - ri;
+    for (int i = 0; i < src.rows * src.cols; ++i)
+      out.data[i] = (uchar)((src.data[3 * i + ri] * 4899 + src.data[3 * i + 1] * 9617 + src.data[3 * i + bi] * 1868 + (1 << 13)) >> 14);
+    dst = out;
+  } else if (code == CV_BGR2Lab) {
+    // GrdPC / CSPC convert to Lab in their constructors (grd_pc.cc:32, cspc.cc:49) and read it only under USE_LAB_WGT, which the
+    // reference leaves undefined (grd_pc.h:25): an image of the right shape, never read
+    dst = Mat::zeros(src.rows, src.cols, CV_8UC3);
   } else {
     throw std::runtime_error("refcheck stand-in: cvtColor code not used by the path");
   }
 }
 inline void Sobel(const Mat &src, Mat &dst, int ddepth, int dx, int dy, int ksize) {
-  CV_Assert(src.type() == CV_32FC1 && ddepth == CV_64F && dx == 1 && dy == 0 && ksize == 1);
+  CV_Assert(ddepth == CV_64F && dx == 1 && dy == 0 && ksize == 1);
   Mat out(src.rows, src.cols, CV_64FC1);
-  csor_sobel_x_ks1(reinterpret_cast<const float *>(src.data), src.cols, src.rows, reinterpret_cast<double *>(out.data));
+  if (src.type() == CV_32FC1) {
+    csor_sobel_x_ks1(reinterpret_cast<const float *>(src.data), src.cols, src.rows, reinterpret_cast<double *>(out.data));
+  } else {  // 8U gray (grd_pc.cc:40, cspc.cc:57): [-1 0 1], BORDER_REFLECT_101, exact integers
+    CV_Assert(src.type() == CV_8UC1);
+    const int w = src.cols;
+    for (int y = 0; y < src.rows; ++y)
+      for (int x = 0; x < w; ++x) {
+        const int xm = x - 1 < 0 ? (w > 1 ? 1 : 0) : x - 1, xp = x + 1 >= w ? (w > 1 ? w - 2 : 0) : x + 1;
+        out.at<double>(y, x) = (double)((int)src.at<uchar>(y, xp) - (int)src.at<uchar>(y, xm));
+      }
+  }
   dst = out;
 }
 inline void minMaxLoc(const Mat &m, double *mn, double *mx) {

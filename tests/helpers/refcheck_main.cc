@@ -15,18 +15,21 @@
 #undef private
 #include "plane_cost/pre_cs_pc.h"
 #include "plane_cost/pre_ss_pc.h"
+#include "plane_cost/grd_pc.h"
+#include "plane_cost/cspc.h"
 #include "cc/grd_cc.h"
+#include "cc/cen_cc.h"
 
 int main(int argc, char **argv) {
   if (argc != 3) { std::fprintf(stderr, "usage: refcheck <in.bin> <out.bin>\n"); return 2; }
   std::ifstream in(argv[1], std::ios::binary);
-  int hdr[8];  // w, h, max_dis, dis_scale, scale_num, iters, use_pp, wnd
+  int hdr[9];  // w, h, max_dis, dis_scale, scale_num, iters, use_pp, wnd, kind (0 GrdCC + PreSSPC/PreCSPC, 1 CenCC + the same, 2 GrdPC / CSPC)
   double lambda;
   unsigned long long seed;
   in.read(reinterpret_cast<char *>(hdr), sizeof hdr);
   in.read(reinterpret_cast<char *>(&lambda), sizeof lambda);
   in.read(reinterpret_cast<char *>(&seed), sizeof seed);
-  const int w = hdr[0], h = hdr[1], max_dis = hdr[2], dis_scale = hdr[3], scale_num = hdr[4], iters = hdr[5], use_pp = hdr[6], wnd = hdr[7];
+  const int w = hdr[0], h = hdr[1], max_dis = hdr[2], dis_scale = hdr[3], scale_num = hdr[4], iters = hdr[5], use_pp = hdr[6], wnd = hdr[7], kind = hdr[8];
   Mat l(h, w, CV_8UC3), r(h, w, CV_8UC3);
   in.read(reinterpret_cast<char *>(l.data), (std::streamsize)w * h * 3);
   in.read(reinterpret_cast<char *>(r.data), (std::streamsize)w * h * 3);
@@ -40,9 +43,12 @@ int main(int argc, char **argv) {
 
   std::stringstream quiet;  // the reference prints its progress to cout
   std::streambuf *keep = std::cout.rdbuf(quiet.rdbuf());
-  GrdCC cc;
-  IPlaneCost *pc = scale_num > 0 ? static_cast<IPlaneCost *>(new PreCSPC(l, r, max_dis, wnd, scale_num, &cc, lambda))
-                                 : static_cast<IPlaneCost *>(new PreSSPC(l, r, max_dis, wnd, &cc));
+  GrdCC grd;
+  CenCC cen;
+  CCMethod *cc = kind == 1 ? static_cast<CCMethod *>(&cen) : static_cast<CCMethod *>(&grd);
+  IPlaneCost *pc;
+  if (kind == 2) pc = scale_num > 0 ? static_cast<IPlaneCost *>(new CSPC(l, r, max_dis, wnd, scale_num, lambda)) : static_cast<IPlaneCost *>(new GrdPC(l, r, max_dis, wnd));
+  else pc = scale_num > 0 ? static_cast<IPlaneCost *>(new PreCSPC(l, r, max_dis, wnd, scale_num, cc, lambda)) : static_cast<IPlaneCost *>(new PreSSPC(l, r, max_dis, wnd, cc));
   std::vector<double> qcost(nq);
   for (int i = 0; i < nq; ++i) {
     const Plane pl(Vec3d(qnp[6 * i], qnp[6 * i + 1], qnp[6 * i + 2]), Point3d(qnp[6 * i + 3], qnp[6 * i + 4], qnp[6 * i + 5]));

@@ -1,6 +1,6 @@
 """The reference's OWN loops next to the oracle (round-4 review, item 7; runs only where /root/reference exists).
 
-cs_patchmatch.cc, plane_cost/pre_ss_pc.cc, plane_cost/pre_cs_pc.cc and cc/grd_cc.cpp are compiled UNMODIFIED, in place, against
+cs_patchmatch.cc, plane_cost/pre_ss_pc.cc, pre_cs_pc.cc, grd_pc.cc, cspc.cc, cc/grd_cc.cpp and cc/cen_cc.cc are compiled UNMODIFIED, in place, against
 test-only stand-ins for <opencv2/opencv.hpp> and <gflags/gflags.h> (tests/helpers/refcheck/): every OpenCV call is delegated to
 the oracle's restated contracts and cv::RNG is the specified counter-based generator in its ROW_SHARED mode (the reference builds
 with USE_OMP and re-seeds every row, cs_patchmatch.cc:129-131).  THIS PINS NOTHING -- a build against stand-ins is not a reference
@@ -21,7 +21,7 @@ from oracle import pyoracle as po
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/CSPM"
 HELP = os.path.join(ROOT, "tests", "helpers")
-SOURCES = ["cs_patchmatch.cc", "plane_cost/pre_ss_pc.cc", "plane_cost/pre_cs_pc.cc", "cc/grd_cc.cpp"]
+SOURCES = ["cs_patchmatch.cc", "plane_cost/pre_ss_pc.cc", "plane_cost/pre_cs_pc.cc", "cc/grd_cc.cpp", "cc/cen_cc.cc", "plane_cost/grd_pc.cc", "plane_cost/cspc.cc"]
 
 pytestmark = pytest.mark.skipif(not all(os.path.exists(os.path.join(REF, s)) for s in SOURCES),
                                 reason="the reference checkout is not on this machine (GPU box)")
@@ -46,11 +46,11 @@ def refcheck_exe(tmp_path_factory):
     return exe
 
 
-def _run_reference(exe, tmp_path, l, r, max_dis, dis_scale, scale_num, lam, iters, use_pp, wnd, seed, queries):
+def _run_reference(exe, tmp_path, l, r, max_dis, dis_scale, scale_num, lam, iters, use_pp, wnd, seed, queries, kind=0):
     h, w = l.shape[:2]
     xyv, npnt = queries
     with open(tmp_path / "in.bin", "wb") as f:
-        f.write(struct.pack("<8i", w, h, max_dis, dis_scale, scale_num, iters, int(use_pp), wnd))
+        f.write(struct.pack("<9i", w, h, max_dis, dis_scale, scale_num, iters, int(use_pp), wnd, kind))
         f.write(struct.pack("<dQ", lam, seed))
         f.write(np.ascontiguousarray(l, np.uint8).tobytes())
         f.write(np.ascontiguousarray(r, np.uint8).tobytes())
@@ -87,18 +87,23 @@ def _queries(rng, n, w, h, max_dis):
 
 
 CASES = [
-    # name, pair, (w, h, max_dis), scale_num, lambda, iters, use_pp, wnd
-    ("ss_noise", "noise", (40, 26, 10), 0, 0.0, 2, True, 9),
-    ("cs_noise", "noise", (44, 30, 12), 3, 0.3, 2, True, 9),
-    ("cs5_lambda0", "noise", (48, 34, 16), 5, 0.0, 1, False, 7),
-    ("cs_blocks", "blocks", (40, 28, 10), 3, 0.3, 2, True, 9),
-    ("ss_black", "black", (36, 24, 8), 0, 0.0, 2, True, 9),
-    ("cs_dup_rows_odd_iters", "dup_rows", (41, 27, 10), 2, 1.0, 3, True, 7),
+    # name, pair, (w, h, max_dis), scale_num, lambda, iters, use_pp, wnd, cost ("GRD" / "CEN": CCMethod + PreSSPC / PreCSPC; "IMG": GrdPC / CSPC)
+    ("ss_noise", "noise", (40, 26, 10), 0, 0.0, 2, True, 9, "GRD"),
+    ("cs_noise", "noise", (44, 30, 12), 3, 0.3, 2, True, 9, "GRD"),
+    ("cs5_lambda0", "noise", (48, 34, 16), 5, 0.0, 1, False, 7, "GRD"),
+    ("cs_blocks", "blocks", (40, 28, 10), 3, 0.3, 2, True, 9, "GRD"),
+    ("ss_black", "black", (36, 24, 8), 0, 0.0, 2, True, 9, "GRD"),
+    ("cs_dup_rows_odd_iters", "dup_rows", (41, 27, 10), 2, 1.0, 3, True, 7, "GRD"),
+    ("census_cs", "noise", (42, 28, 10), 3, 0.3, 2, True, 9, "CEN"),
+    ("census_ss_blocks", "blocks", (40, 26, 8), 0, 0.0, 2, True, 9, "CEN"),
+    ("grdpc", "noise", (40, 26, 10), 0, 0.0, 2, True, 9, "IMG"),
+    ("cspc", "noise", (44, 30, 12), 3, 0.3, 2, True, 9, "IMG"),
+    ("cspc_periodic", "periodic", (40, 26, 10), 2, 0.3, 2, True, 7, "IMG"),
 ]
 
 
-@pytest.mark.parametrize("name,kind,dims,scale_num,lam,iters,use_pp,wnd", CASES, ids=[c[0] for c in CASES])
-def test_reference_loops_equal_the_oracle(refcheck_exe, tmp_path, name, kind, dims, scale_num, lam, iters, use_pp, wnd):
+@pytest.mark.parametrize("name,kind,dims,scale_num,lam,iters,use_pp,wnd,cc", CASES, ids=[c[0] for c in CASES])
+def test_reference_loops_equal_the_oracle(refcheck_exe, tmp_path, name, kind, dims, scale_num, lam, iters, use_pp, wnd, cc):
     w, h, max_dis = dims
     dis_scale, seed = 16, 4321
     if kind == "noise":
@@ -107,13 +112,14 @@ def test_reference_loops_equal_the_oracle(refcheck_exe, tmp_path, name, kind, di
         l, r = synth.make_adversarial(kind, w, h, max_dis, seed=3)
     rng = np.random.default_rng(7)
     queries = _queries(rng, 60, w, h, max_dis)
-    qcost, views = _run_reference(refcheck_exe, tmp_path, l, r, max_dis, dis_scale, scale_num, lam, iters, use_pp, wnd, seed, queries)
+    qcost, views = _run_reference(refcheck_exe, tmp_path, l, r, max_dis, dis_scale, scale_num, lam, iters, use_pp, wnd, seed, queries,
+                                  kind={"GRD": 0, "CEN": 1, "IMG": 2}[cc])
     # the oracle: reference order (serial sweep, serial window sum), one thread, the row-shared random streams of the reference's USE_OMP build
-    pc = po.PlaneCost(l, r, max_dis, wnd, scale_num, lam)
+    pc = po.PlaneCost(l, r, max_dis, wnd, scale_num, lam, cc=cc)
     xyv, npnt = queries
     want = np.array([pc.cost(xyv[i, 0], xyv[i, 1], npnt[i, :3], po.plane_param(npnt[i, :3], npnt[i, 3:]), xyv[i, 2], po.SUM_SERIAL)
                      for i in range(len(xyv))])
-    np.testing.assert_array_equal(qcost, want, err_msg="GetPlaneCost (pre_ss_pc.cc:74-118 / pre_cs_pc.cc:133-188)")
+    np.testing.assert_array_equal(qcost, want, err_msg="GetPlaneCost (pre_ss_pc.cc:74-118 / pre_cs_pc.cc:133-188 / grd_pc.cc:72-176 / cspc.cc:107-183)")
     pm = po.PatchMatch(l, r, max_dis, dis_scale)
     pm.run(iters, pc, use_pp, seed=seed, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL, rng_mode=po.RNG_ROW_SHARED, threads=1)
     for v in (0, 1):
