@@ -204,8 +204,7 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
           c0 = left ? chi : clo;
           c1 = left ? clo : chi;
         } else {
-          c0 = cell_of<SRC>(lut.a, F.P, F.o0[k]);
-          c1 = cell_of<SRC>(lut.a, F.P, F.o1[k]);
+          cell_pair_of<SRC>(lut.a, F.P, F.o0[k], F.o1[k], c0, c1);
         }
         acc[k] = __builtin_fma(wgt, tap_value(F.d[k], c0, c1, A.maxc), acc[k]);  // :176-177
       }
@@ -372,12 +371,10 @@ __device__ __forceinline__ void chain_passes(const Cost &cd, const ChainLevel &A
 #if defined(CSPM_SWEEP_TRACE) && defined(CSPM_STEP_TRACE)
           const uint4 o0 = ld_elem<SRC>(A.opx, of), o1 = ld_elem<SRC>(A.opx, of + A.dirE);
           if (c == 0) STEP_STAMP(3, o0.x, o1.x);
-          c0 = cell_of<SRC>(lut.a, P, o0);
-          c1 = cell_of<SRC>(lut.a, P, o1);
+          cell_pair_of<SRC>(lut.a, P, o0, o1, c0, c1);
           if (c == 0) STEP_STAMP(4, __double2hiint(c0), __double2hiint(c1));
 #else
-          c0 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of));
-          c1 = cell_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of + A.dirE));
+          cell_pair_of<SRC>(lut.a, P, ld_elem<SRC>(A.opx, of), ld_elem<SRC>(A.opx, of + A.dirE), c0, c1);
 #endif
         }
         acc[c] = __builtin_fma(wgt, ALLV ? lerp_cells(d.fr, c0, c1) : tap_value(d, c0, c1, A.maxc), acc[c]);  // :176-177

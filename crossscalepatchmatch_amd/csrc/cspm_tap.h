@@ -106,6 +106,53 @@ __device__ __forceinline__ double cell_of(const double *lut_a, const uint4 &own,
   return grd_cell(lut_a, pix_of<SRC>(own), g_of(own), pix_of<SRC>(other), g_of(other));
 }
 
+// LDS is addressed with plain 32-bit byte addresses (lds_ld): a tap's address is then ONE integer operation on top of the
+// per-row lane constant, every other displacement is an instruction immediate (through generic pointers the compiler re-adds
+// the strip base per tap and cannot fold negative displacements).
+typedef __attribute__((address_space(3))) const char lds_cchar;
+__device__ __forceinline__ int lds_addr(const void *p) { return (int)(uintptr_t)(lds_cchar *)p; }
+template <class T> struct LdsVec { typedef T type; };
+template <> struct LdsVec<uint2> { typedef u32x2 type; };
+template <> struct LdsVec<uint4> { typedef u32x4 type; };
+template <class T>
+__device__ __forceinline__ T lds_ld(int adr) {
+  typedef typename LdsVec<T>::type V;
+  const V v = *(__attribute__((address_space(3))) const V *)(uintptr_t)(unsigned)adr;
+  if constexpr (sizeof(T) == 16) return T{v[0], v[1], v[2], v[3]};
+  else if constexpr (__is_floating_point(T)) return v;
+  else if constexpr (sizeof(T) == 8) return T{v[0], v[1]};
+  else return v;
+}
+// The two cells of a tap (own pixel against the other view's pixels at f and f + 1) with the colour look-ups formed together: both SADs
+// in one register (v_sad_u8 / v_sad_hi_u8: <= 765 each, 16 bits apart), ONE packed minimum against kClrSat, and the LDS addresses of the two
+// table entries with one instruction each (v_mad_u32_u16: a 16-bit half * 8 + table) -- five instructions where two grd_cell() take six.  The same table entries, the same
+// arithmetic after them: the bits of grd_cell().  `lut_a_adr`: lds_addr() of Luts::a (a workgroup's tables live in LDS, load_luts).
+#ifndef CSPM_PAIR_SAD
+#define CSPM_PAIR_SAD 1
+#endif
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+template <int SRC>
+__device__ __forceinline__ void cell_pair_of(const double *lut_a, const uint4 &own, const uint4 &o0, const uint4 &o1, double &c0, double &c1) {
+  if constexpr (SRC == kSrcCen || !CSPM_PAIR_SAD) {
+    c0 = cell_of<SRC>(lut_a, own, o0);
+    c1 = cell_of<SRC>(lut_a, own, o1);
+  } else {
+    const uint32_t Iq = pix_of<SRC>(own);
+    const double Gq = g_of(own);
+    uint32_t t = __builtin_amdgcn_sad_u8(Iq, pix_of<SRC>(o0), 0u);
+    t = __builtin_amdgcn_sad_hi_u8(Iq, pix_of<SRC>(o1), t);
+    const u16x2_t lim = {(unsigned short)kClrSat, (unsigned short)kClrSat};
+    t = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, t), lim));
+    const int base = lds_addr(lut_a);
+    int adr0;
+    asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(adr0) : "v"(t), "s"(base));  // (t & 0xffff) * 8 + table
+    int adr1;
+    asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(adr1) : "v"(t), "s"(base));  // (t >> 16) * 8 + table
+    const double a0 = lds_ld<double>(adr0), a1 = lds_ld<double>(adr1);
+    c0 = __builtin_fma(1 - 0.1, __builtin_fmin(fabs(Gq - g_of(o0)), 2.0), a0);  // grd_cell()'s last two steps
+    c1 = __builtin_fma(1 - 0.1, __builtin_fmin(fabs(Gq - g_of(o1)), 2.0), a1);
+  }
+}
 // v_cvt_i32_f64 saturates and maps NaN to 0; written as asm because (int)double is undefined out of range.
 __device__ __forceinline__ int cvt_i32_sat(double x) {
   int r;
