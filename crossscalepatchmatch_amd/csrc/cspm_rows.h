@@ -48,6 +48,9 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_ROW_EXIT
 #define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
 #endif
+#ifndef CSPM_EDGE_ALLV
+#define CSPM_EDGE_ALLV 1   // waves at the image's left / right border: all-valid taps (with the column mask) on the rows that allow it
+#endif
 #ifndef CSPM_TABLE_DMA
 #define CSPM_TABLE_DMA 1   // cell tables filled by LDS-DMA from the level's device-cell volume when the cost object carries one (0: always computed)
 #endif
@@ -1058,17 +1061,21 @@ __device__ CSPM_LEVEL_INLINE double level_rows(const Cost &cd, const Luts &lut, 
         Rr.adr_o += boff; Rr.adr_g += boff; Rr.adr_g2 += boff; Rr.adr_g3 += boff; Rr.adr_p += boff; Rr.img_base += boff;
         const double rowterm = b * (double)qy + c;  // q_disp_y, :155
         double Rsum;
+        // see the register-staged loop below for the all-valid test.  It looks at the window's end columns whether or not they are inside
+        // the image: a wave at the image border (column mask) whose rows pass reads valid strip slots (the padded columns) for its masked
+        // taps too, and takes the all-valid taps with the mask.
+        const int jl = (A.n - 1) % kRowMod;
+        const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
+        const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
+        const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
+        const bool safe = (L.D >= 2) & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
+        const bool allv = __builtin_amdgcn_ballot_w64(!safe) == 0ull;
         if (!edge) {
-          // see the register-staged loop below for the all-valid test
-          const int jl = (A.n - 1) % kRowMod;
-          const double q_first = tap_disp(a, 0.0, group_disp(a, qx0_d, rowterm));
-          const double q_last = tap_disp(a, (double)jl, group_disp(a, qx0_d + (double)(A.n - 1 - jl), rowterm));
-          const double lo = 1.0 + 0x1p-20, hi = (double)L.D - 0x1p-20;
-          const bool safe = (L.D >= 2) & (L.D < 512) & (q_first >= lo) & (q_first <= hi) & (q_last >= lo) & (q_last <= hi);
-          Rsum = __builtin_amdgcn_ballot_w64(!safe) == 0ull ? row_taps<SRC, VIEW, false, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
-                                                            : row_taps<SRC, VIEW, false, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+          Rsum = allv ? row_taps<SRC, VIEW, false, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
+                      : row_taps<SRC, VIEW, false, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
         } else {
-          Rsum = row_taps<SRC, VIEW, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
+          Rsum = (CSPM_EDGE_ALLV && allv) ? row_taps<SRC, VIEW, true, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx)
+                                          : row_taps<SRC, VIEW, true, true>(A, lut, Rr, Ip, a, rowterm, qx0_d, e_lo, e_span, qy, cx);
         }
         tree.push(dy, Rsum);
 #ifdef CSPM_ROW_STATS
