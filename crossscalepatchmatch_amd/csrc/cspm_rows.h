@@ -48,6 +48,12 @@ constexpr int kRowWaves = CSPM_ROW_WAVES;     // waves per workgroup (they share
 #ifndef CSPM_ROW_EXIT
 #define CSPM_ROW_EXIT 1   // early exit tested after every window row (0: at level ends only)
 #endif
+#ifndef CSPM_CELL_BUMP
+#define CSPM_CELL_BUMP 1   // table rows with an immediate pitch: likewise (cell_row_taps)
+#endif
+#ifndef CSPM_ROW_BUMP
+#define CSPM_ROW_BUMP 1    // general rows: the groups of seven step their LDS bases by hand (row_taps)
+#endif
 #ifndef CSPM_EDGE_ALLV
 #define CSPM_EDGE_ALLV 1   // waves at the image's left / right border: all-valid taps (with the column mask) on the rows that allow it
 #endif
@@ -401,15 +407,16 @@ __device__ __forceinline__ void tap_batch(const RowLevel &A, const Luts &lut, co
 //   EDGE   : some lane's window leaves the image in x -> per-tap mask (e_rel = g0 - e_lo per lane, e_span)
 //   STAGED : operands come from the two LDS strips, else from global memory
 template <int SRC, int VIEW, bool EDGE, bool STAGED, bool ALLV, int CNT>
-__device__ __forceinline__ void tap_group(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, uint32_t Ip, double pa, double rowterm,
+__device__ __forceinline__ void tap_group(const RowLevel &A, const Luts &lut, const RowSrc &R, int g0, int ga, uint32_t Ip, double pa, double rowterm,
                                           double &qxg_d, int e_rel, int e_span, int qy, int cx_lane, double S[kRowMod]) {
   constexpr int E = elem_size<SRC>();
   constexpr int SUB = CSPM_ROW_SUB;
   const double Gg = group_disp(pa, qxg_d, rowterm);  // the group's disparity base (device order, cspm_tap.h)
   const double qxg = qxg_d;
   qxg_d += (double)kRowMod;                          // exact: small integers
-  const int adr_o = R.adr_o + g0 * 16, adr_g = R.adr_g + g0 * (SRC == kSrcCen ? 16 : 8), adr_p = R.adr_p + g0 * 4, off_g = R.lane_off + g0 * E;
-  const int adr_g2 = R.adr_g2 + g0 * (SRC == kSrcCen ? 16 : 8), adr_g3 = R.adr_g3 + g0 * (SRC == kSrcCen ? 16 : 8);
+  // ga: the group's first window column as far as the addresses go (g0, or 0 when row_taps steps the bases itself)
+  const int adr_o = R.adr_o + ga * 16, adr_g = R.adr_g + ga * (SRC == kSrcCen ? 16 : 8), adr_p = R.adr_p + ga * 4, off_g = R.lane_off + ga * E;
+  const int adr_g2 = R.adr_g2 + ga * (SRC == kSrcCen ? 16 : 8), adr_g3 = R.adr_g3 + ga * (SRC == kSrcCen ? 16 : 8);
   tap_batch<SRC, VIEW, EDGE, STAGED, ALLV, 0, (CNT < SUB ? CNT : SUB)>(A, lut, R, g0, adr_o, adr_g, adr_g2, adr_g3, adr_p, off_g, Ip, pa, Gg, qxg, e_rel, e_span, qy,
                                                                   cx_lane, S);
   if constexpr (CNT > SUB)
@@ -429,11 +436,22 @@ __device__ __forceinline__ double row_taps(const RowLevel &A, const Luts &lut, c
   double qx_d = qx0_d;
   const int full = A.n / kRowMod * kRowMod;
   int g0 = 0;
-  for (; g0 < full; g0 += kRowMod)
-    tap_group<SRC, VIEW, EDGE, STAGED, ALLV, kRowMod>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
+  if constexpr (CSPM_ROW_BUMP && STAGED && SRC == kSrcGrd) {
+    // The three LDS bases are stepped by hand and laundered: left to itself the loop optimiser keeps bases WITHOUT the row's buffer offset
+    // and re-adds it in every group (seven address additions per group instead of three).
+    RowSrc Rg = R;
+    for (; g0 < full; g0 += kRowMod) {
+      tap_group<SRC, VIEW, EDGE, STAGED, ALLV, kRowMod>(A, lut, Rg, g0, 0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
+      Rg.adr_o += kRowMod * 16; Rg.adr_g += kRowMod * 8; Rg.adr_p += kRowMod * 4;
+      asm("" : "+v"(Rg.adr_o), "+v"(Rg.adr_g), "+v"(Rg.adr_p));
+    }
+  } else {
+    for (; g0 < full; g0 += kRowMod)
+      tap_group<SRC, VIEW, EDGE, STAGED, ALLV, kRowMod>(A, lut, R, g0, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S);
+  }
   // window sizes that are not a multiple of 7 (the usual 35 is): the remaining 1..6 taps
   switch (A.n - full) {
-#define CSPM_TAIL(K) case K: tap_group<SRC, VIEW, EDGE, STAGED, ALLV, K>(A, lut, R, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S); break;
+#define CSPM_TAIL(K) case K: tap_group<SRC, VIEW, EDGE, STAGED, ALLV, K>(A, lut, R, g0, g0, Ip, pa, rowterm, qx_d, g0 - e_lo, e_span, qy, cx_lane, S); break;
     CSPM_TAIL(1) CSPM_TAIL(2) CSPM_TAIL(3) CSPM_TAIL(4) CSPM_TAIL(5) CSPM_TAIL(6)
 #undef CSPM_TAIL
     default: break;
@@ -535,7 +553,21 @@ __device__ __forceinline__ double cell_row_taps(const RowLevel &A, const Luts &l
   if constexpr (PITCH_IMM && CSPM_CELL_PITCH_IMM) {
     done = true;
     switch (C.stride) {
+#if CSPM_CELL_BUMP
+      // (the table and weight / colour bases stepped by hand and laundered, as in row_taps: two address additions per group instead of four)
+#define CSPM_PITCH(P)                                                                    \
+  case P * 8: {                                                                          \
+    CellRow Cg = C;                                                                      \
+    for (; g0 < full; g0 += kRowMod) {                                                   \
+      cell_group<ALLV, WTAB, kRowMod, P * 8>(A, lut, Cg, 0, pa, rowterm, qx_d, S);       \
+      Cg.adr_c += kRowMod * 8;                                                           \
+      if constexpr (WTAB) { Cg.adr_w += kRowMod * 8; asm("" : "+v"(Cg.adr_c), "+v"(Cg.adr_w)); } \
+      else { Cg.adr_p += kRowMod * 4; asm("" : "+v"(Cg.adr_c), "+v"(Cg.adr_p)); }       \
+    }                                                                                    \
+  } break;
+#else
 #define CSPM_PITCH(P) case P * 8: for (; g0 < full; g0 += kRowMod) cell_group<ALLV, WTAB, kRowMod, P * 8>(A, lut, C, g0, pa, rowterm, qx_d, S); break;
+#endif
       CSPM_PITCH(128) CSPM_PITCH(100) CSPM_PITCH(80) CSPM_PITCH(68) CSPM_PITCH(52) CSPM_PITCH(44) CSPM_PITCH(40)
 #undef CSPM_PITCH
       default: done = false; break;
