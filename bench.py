@@ -387,8 +387,8 @@ def main():
                 "note": "bound = VALU issue: the tap stream never leaves the chip (see traffic vs algorithmic_bytes_per_launch), HBM at %.1f x its "
                         "peak by the algorithmic-byte yardstick.  frac = algorithmic f64 operations (14 per tap x in-image taps of one launch) / "
                         "launch time / 3.93e13 lane-op/s (78.6 TFLOP/s f64 vector, an FMA counted once).  frac is a yardstick of the REFERENCE's "
-                        "operation count, not a distance to an attainable 1.0: the kernel's table rows execute fewer VALU instructions per tap (8.1-10.3) "
-                        "than the 14 operations they are credited with, its general rows more (22-27); see valu_winstr_per_64_algorithmic_taps for "
+                        "operation count, not a distance to an attainable 1.0: the kernel's table rows execute fewer VALU instructions per tap (7.9-9.9) "
+                        "than the 14 operations they are credited with, its general rows more (21-25); see valu_winstr_per_64_algorithmic_taps for "
                         "what was actually issued." % (alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS),
             }
             # instruction-level view of the same launch from the committed rocprofv3 --pmc passes -- quoted only while the file
