@@ -125,8 +125,9 @@ __device__ __forceinline__ T lds_ld(int adr) {
 }
 // The two cells of a tap (own pixel against the other view's pixels at f and f + 1) with the colour look-ups formed together: both SADs
 // in one register (v_sad_u8 / v_sad_hi_u8: <= 765 each, 16 bits apart), ONE packed minimum against kClrSat, and the LDS addresses of the two
-// table entries with one instruction each (v_mad_u32_u16: a 16-bit half * 8 + table) -- five instructions where two grd_cell() take six.  The same table entries, the same
-// arithmetic after them: the bits of grd_cell().  `lut_a_adr`: lds_addr() of Luts::a (a workgroup's tables live in LDS, load_luts).
+// table entries with one instruction each (v_mad_u32_u16: a 16-bit half * 8 + table) -- five instructions where two grd_cell() take six.
+// The same table entries, the same arithmetic after them: the bits of grd_cell().  `lut_a` MUST point into LDS (Luts::a of load_luts():
+// every kernel of the two tap engines; the volume builders, whose table is in global memory, call grd_cell()).
 #ifndef CSPM_PAIR_SAD
 #define CSPM_PAIR_SAD 1
 #endif
