@@ -588,7 +588,7 @@ static inline int trunc_x86(double q) {
  * cost it multiplies; q_disp is the caller's (the two summation orders form it differently, see level_cost).
  * dev != 0: the device order's cells and its contracted interpolation c0 + fr*(c1 - c0) as ONE fma -- the same value as
  * floor_wgt*c0 + (1-floor_wgt)*c1 up to rounding (floor_wgt = 1 - fr and 1 - floor_wgt = fr exactly for a valid tap). */
-static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p, int q_x, int q_y,
+static inline __attribute__((always_inline)) double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p, int q_x, int q_y,
                          double q_disp, int dev, double *wgt_out) {
   const uint8_t *I_q = pc->img[view][s] + ((size_t)q_y * pc->wid[s] + q_x) * 3;
   int sum = abs(I_p[0] - I_q[0]) + abs(I_p[1] - I_q[1]) + abs(I_p[2] - I_q[2]);
@@ -632,6 +632,14 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
   return floor_wgt * c0[0] + (1 - floor_wgt) * c0[slab];
 }
 
+/* Speed only: a second copy of level_cost for CPUs with FMA3, picked at load time.  fma() is correctly rounded by definition, so the
+ * inlined vfmadd instruction and libm's fma() return the same bits; -ffp-contract=off still forbids the compiler to contract any
+ * OTHER expression in either copy.  (A whole KITTI-size pair in the device order: 156 s -> about 100 s of the GPU suite.) */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define CSOR_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define CSOR_FMA_CLONES
+#endif
 #define ROWMOD_K 7   /* CSOR_SUM_DEVICE: interleaved partial sums per window row */
 #define ROWTREE_N 64 /* ... and a balanced binary tree over the window rows (window sizes up to 45 < 64) */
 
@@ -652,6 +660,7 @@ static inline double tap(const csor_pc *pc, int view, int s, const uint8_t *I_p,
  *     single lane computes with a binary-counter stack of six pending partial sums.
  *   Taps outside the image are skipped (adding +0.0 changes nothing: every partial sum starts at +0.0).
  *   Same terms as the serial order, other rounding. */
+CSOR_FMA_CLONES
 static int level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double a, double b, double c,
                       int sum_order, double base, double mul, double thresh, int use_thresh, long long *taps, double *sum) {
   const int half = pc->half_wnd, W = pc->wid[s], H = pc->hei[s];
@@ -678,15 +687,17 @@ static int level_cost(const csor_pc *pc, int view, int s, int cx, int cy, double
     } else {
       double S[ROWMOD_K];
       for (int j = 0; j < ROWMOD_K; ++j) S[j] = 0.0;
-      for (int dx = -half; dx <= half; ++dx) {
-        int q_x = cx + dx;
-        const int col = dx + half, j = col % ROWMOD_K;
-        if (q_x >= 0 && q_x < W) {
-          const double G = fma(a, (double)(q_x - j), q_disp_y);
-          double wgt;
-          const double t = tap(pc, view, s, I_p, q_x, q_y, fma(a, (double)j, G), 1, &wgt);
-          S[j] = fma(wgt, t, S[j]);
-          ++nt;
+      for (int col0 = 0; col0 <= 2 * half; col0 += ROWMOD_K) { /* groups of 7 window columns; column col0 + j feeds S[j] */
+        const int x0 = cx - half + col0;
+        const double G = fma(a, (double)x0, q_disp_y);
+        for (int j = 0; j < ROWMOD_K && col0 + j <= 2 * half; ++j) {
+          const int q_x = x0 + j;
+          if (q_x >= 0 && q_x < W) {
+            double wgt;
+            const double t = tap(pc, view, s, I_p, q_x, q_y, fma(a, (double)j, G), 1, &wgt);
+            S[j] = fma(wgt, t, S[j]);
+            ++nt;
+          }
         }
       }
       double r = S[0];
