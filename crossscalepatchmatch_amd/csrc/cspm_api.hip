@@ -16,7 +16,7 @@ using namespace cspm;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // error of a failed cspm_create, per calling thread (cspm_last_error(NULL))
 
 struct TimingRec {
   int kclass;
@@ -95,7 +95,10 @@ struct cspm_ctx {
   unsigned int *d_px8_bad = nullptr;        // device counter: gradients k_make_px8 could not pack (must stay 0)
   double volumes_mem_fraction = 0.5;        // of the memory hipMemGetInfo reports free when a cost object is allocated, the share the optional volumes (cvol, vol2) may take (env CSPM_VOLUMES_MEM_FRACTION)
   long long optional_volume_fallbacks = 0;  // times a hipMalloc of an optional volume failed and the pair went on without (CSPM_OPT_VOLUME_FALLBACKS)
-  int fault_volume_alloc = 0;               // fault injection for the tests: the n-th optional-volume allocation of this context fails (env CSPM_FAULT_VOLUME_ALLOC)
+  bool optional_missing = false;            // the current cost object wanted optional volumes and runs without them
+  long long optional_reuses = 0;            // pairs that reused it since
+  long long volume_retry_pairs = 16;        // CSPM_OPT_VOLUME_RETRY_PAIRS: ask again for the volumes every so many reuses (0 = never)
+  int fault_volume_alloc = 0;               // fault injection for the tests: the n-th optional-volume allocation of this context fails (CSPM_OPT_FAULT_VOLUME_ALLOC, a test hook: nothing in the environment reaches it)
   unsigned long long *d_maxkeys = nullptr;
   int row_claim = -1;  // row kernels: -1 = claimed column bands for launches of several rounds (default), 0 / 1 = never / always (env CSPM_ROW_CLAIM, tests)
   unsigned int *d_rowq = nullptr;  // row kernels: the eight claim counters of a launch that claims its items (cspm_rows.h row_item)
@@ -443,8 +446,16 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
   key.with_cvol = with_cvol;
   const bool with_px8 = kind == kKindGrd && !with_vol && c->opt_sweep_packed != 0;
   key.with_px8 = with_px8;
-  const bool reuse = c->cost_alloc && key == c->cost_key;
-  if (!reuse) free_cost(c);
+  bool reuse = c->cost_alloc && key == c->cost_key;
+  // A cost object that wanted optional volumes and did not get them (free-memory veto, failed hipMalloc) is reused as it is, but not for
+  // ever: every volume_retry_pairs-th reuse allocates afresh and asks again, so that one transient shortage -- another context was
+  // building its own volumes at that moment -- does not leave this context on the slower path until its geometry changes.
+  if (reuse && c->optional_missing && c->volume_retry_pairs > 0 && ++c->optional_reuses >= c->volume_retry_pairs) reuse = false;
+  if (!reuse) {
+    free_cost(c);
+    c->optional_reuses = 0;
+    c->optional_missing = false;
+  }
   Cost &cd = c->cost;
   c->cost_ready = false;
   c->max_cost_fetched = false;
@@ -562,6 +573,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
         }
       }
     }
+    c->optional_missing = (key.with_cvol && !with_cvol) || (key.with_pairs && !with_pairs);  // wanted, not held: asked for again later
     double lut[2 * kLutSize];
     for (int i = 0; i < kLutSize; ++i) {
       lut[i] = std::exp(-i * 1.0 / 10.0);  // WGT_GAMMA, pre_cs_pc.h:16
@@ -586,6 +598,7 @@ int alloc_cost(cspm_ctx *c, int max_dis, int wnd_size, int scale_num, double reg
     c->cost_alloc = true;
   }
   launch_pyramid(c);
+  HIPCHK(c, hipMemsetAsync(c->d_px8_bad, 0, sizeof(unsigned int), c->stream));  // per cost object, not per allocation
   // scale weights (pre_cs_pc.cc:86-109): host-side, per call (reg_lambda is not part of the buffer key)
   if (cd.cs) {
     if (scale_weights(cd.levels, reg_lambda, c->scale_wgt)) return fail(c, CSPM_ERR_ARG, "singular regularisation matrix");
@@ -651,12 +664,6 @@ int ensure_field(cspm_ctx *c) {
   HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl, 0, (2 + kSweepMaxBands) * sizeof(unsigned int), c->stream));
   if ((rc = dalloc(c, &c->d_sweep_gran, 2 * n * kGranPerPixel, nullptr))) return rc;
   HIPCHK(c, hipMemsetAsync(c->d_sweep_gran, 0, sizeof(unsigned long long) * 2 * n * kGranPerPixel, c->stream));
-  // dataflow sweep: predecessor counters (zeroed before every sweep), the queue of ready pixels (epoch-tagged entries: never cleared;
-  // at most one entry per pixel plus one reserved slot per waiting workgroup) and its control words
-  if ((rc = dalloc(c, &c->d_sweep_ready, 2 * n, nullptr))) return rc;
-  if ((rc = dalloc(c, &c->d_sweep_queue, 2 * n + 65536, nullptr))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->d_sweep_queue, 0, sizeof(unsigned long long) * (2 * n + 65536), c->stream));
-  if ((rc = dalloc(c, &c->d_sweep_qctl, 4, nullptr))) return rc;
   c->sweep_epoch = 0;
   {
     // per row band b (sweep rows [b*H/nb, (b+1)*H/nb)): start[k] = the band's items (both views) on anti-diagonals < k
@@ -676,6 +683,21 @@ int ensure_field(cspm_ctx *c) {
     c->sweep_bands_built = nb;
   }
   c->field_alloc = true;
+  return CSPM_OK;
+}
+
+// dataflow sweep (CSPM_OPT_SWEEP_FLOW, off by default): predecessor counters (zeroed before every sweep), the queue of ready pixels
+// (epoch-tagged entries: never cleared; at most one entry per pixel plus one reserved slot per waiting workgroup) and its control
+// words -- 24 bytes per pixel that the default sweep never touches, so they are allocated by the first sweep that wants them
+// (free_field releases them).
+int ensure_flow(cspm_ctx *c) {
+  if (c->d_sweep_ready) return CSPM_OK;
+  const size_t n = (size_t)c->W * c->H;
+  int rc;
+  if ((rc = dalloc(c, &c->d_sweep_ready, 2 * n, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->d_sweep_queue, 2 * n + 65536, nullptr))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sweep_queue, 0, sizeof(unsigned long long) * (2 * n + 65536), c->stream));
+  if ((rc = dalloc(c, &c->d_sweep_qctl, 4, nullptr))) return rc;
   return CSPM_OK;
 }
 
@@ -700,10 +722,20 @@ int enqueue_postprocess_device(cspm_ctx *c, int dis_scale, void *d_l_out, void *
 
 int check_sweep(cspm_ctx *c) {
   if (!c->sweep_pending) return CSPM_OK;
-  unsigned int ctrl[2] = {0, 0};
+  unsigned int ctrl[2] = {0, 0}, px8_bad = 0;
   HIPCHK(c, hipMemcpyAsync(ctrl, c->d_sweep_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, c->stream));
+  const bool packed = c->sweep_packed && c->cost_alloc && c->d_px8_bad;
+  if (packed) HIPCHK(c, hipMemcpyAsync(&px8_bad, c->d_px8_bad, sizeof px8_bad, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sweep_pending = false;
+  // CSPM_OPT_SWEEP_PACKED: a gradient the 36-bit fixed-point field cannot hold was packed as 0 and the sweep read a wrong cell.  Cannot
+  // happen for 8-bit images (cspm.h); if it ever does, the planes are wrong and the caller must hear about it, not only a counter.
+  if (packed && px8_bad) {
+    c->pm_runs_unchecked = 0;
+    c->phases_unchecked = false;
+    c->out_reqs.clear();
+    return fail(c, CSPM_ERR_HIP, "CSPM_OPT_SWEEP_PACKED: " + std::to_string(px8_bad) + " gradients could not be packed exactly; the raster sweep's planes are not valid");
+  }
   const int runs = c->pm_runs_unchecked;
   const bool phases = c->phases_unchecked;
   c->pm_runs_unchecked = 0;
@@ -755,7 +787,9 @@ int check_pm(cspm_ctx *c, const cspm_pm_params **p) {
 // needs a little more -- gfx950 has 160 KB per CU -- and a kernel has to opt in once per instantiation.
 template <class K>
 inline void allow_lds(K kern, size_t shmem) {
-  if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  // always the device's whole 160 KB: the attribute belongs to the kernel, not to the launch, and two host threads (two contexts)
+  // that set two different sizes for the same instantiation would race between one's attribute call and its launch
+  if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 #define LAUNCH_ONE(K, grid, block, shmem, ...)                                \
   do {                                                                       \
@@ -852,6 +886,8 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     HIPCHK(c, hipMemsetAsync(c->d_sweep_ctrl + 2, 0, kSweepMaxBands * sizeof(unsigned int), c->stream));  // the claim counters; ctrl[1] is sticky
     const bool flow = c->opt_sweep_flow != 0 && (long long)c->W * c->H < (1LL << 30);
     if (flow) {
+      int frc = ensure_flow(c);
+      if (frc) return frc;
       sw.ready[0] = c->d_sweep_ready;
       sw.ready[1] = c->d_sweep_ready + (size_t)c->W * c->H;
       sw.queue = c->d_sweep_queue;
@@ -1019,7 +1055,6 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_SWEEP_PACKED")) c->opt_sweep_packed = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_SWEEP_FLOW")) c->opt_sweep_flow = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
-  if (const char *e = getenv("CSPM_FAULT_VOLUME_ALLOC")) c->fault_volume_alloc = atoi(e);
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -1136,6 +1171,8 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_SWEEP_PACKED: c->opt_sweep_packed = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: c->opt_sweep_flow = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: c->sweep_wg_per_cu = value < 0 ? 0 : (value > 16 ? 16 : (int)value); return CSPM_OK;
+    case CSPM_OPT_FAULT_VOLUME_ALLOC: c->fault_volume_alloc = value < 0 ? 0 : (int)value; return CSPM_OK;
+    case CSPM_OPT_VOLUME_RETRY_PAIRS: c->volume_retry_pairs = value < 0 ? 0 : value; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
       if (value < 0 || value > 3600000) return fail(c, CSPM_ERR_ARG, "sweep timeout out of range");
       c->sweep_timeout_ms = value;
@@ -1156,6 +1193,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_TABLE_VOLUMES_ACTIVE: *value = (c->cost_alloc && c->cost.lv[0].cvol[0]) ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
+    case CSPM_OPT_VOLUME_RETRY_PAIRS: *value = c->volume_retry_pairs; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: *value = c->opt_sweep_flow; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: *value = c->sweep_wg_per_cu; return CSPM_OK;

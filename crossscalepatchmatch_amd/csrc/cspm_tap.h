@@ -252,6 +252,15 @@ __device__ __forceinline__ double img_cell(uint32_t Iq, double Gq, uint32_t If, 
 // neighbouring group is a valid source: xor 1 and xor 2 are quad permutes, the 4-lane groups meet by row_half_mirror (i <-> 7-i), the
 // 8-lane groups by row_mirror (i <-> 15-i), and the four 16-lane rows are read out with v_readlane: (r0+r1) + (r2+r3) is what the lanes
 // of rows 0-1 computed with __shfl_xor, (r2+r3) + (r0+r1) what rows 2-3 did -- the same bits.
+// PRECONDITION of wave_tree_sum / wave_min_i32 / wave_max_i32: ALL 64 LANES ACTIVE (EXEC == ~0).  A disabled source lane leaves the DPP
+// destination unchanged and v_readlane of a disabled lane returns stale register contents -- neither faults, both give a wrong sum.
+// Every caller keeps the whole wave alive (tail lanes shadow a real pixel and are masked at the store); builds with -DCSPM_DEBUG_EXEC trap
+// when that is ever not so.
+__device__ __forceinline__ void require_full_exec() {
+#ifdef CSPM_DEBUG_EXEC
+  if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -263,6 +272,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 __device__ __forceinline__ double wave_tree_sum(double v) {
+  require_full_exec();
   v = v + dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
   v = v + dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
   v = v + dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the 8
@@ -278,6 +288,7 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 __device__ __forceinline__ int wave_min_i32(int v) {
+  require_full_exec();
   v = min(v, dpp_i32<0xB1>(v));
   v = min(v, dpp_i32<0x4E>(v));
   v = min(v, dpp_i32<0x141>(v));
@@ -285,6 +296,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return __builtin_amdgcn_readfirstlane(min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48))));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
+  require_full_exec();
   v = max(v, dpp_i32<0xB1>(v));
   v = max(v, dpp_i32<0x4E>(v));
   v = max(v, dpp_i32<0x141>(v));

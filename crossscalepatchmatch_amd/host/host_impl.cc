@@ -1,5 +1,6 @@
 // host_impl.cc -- GrdCC, DevicePlaneCost (PreSSPC / PreCSPC) and CSPatchMatch above the C ABI of
 // libcspm_hip.so.  No arithmetic of the hot path happens here.
+#include <mutex>
 #include <vector>
 
 #include "../../include/cspm.h"
@@ -52,76 +53,150 @@ void CenCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int ri
 void CenCC::buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol) { build(lImg, rImg, maxDis, costVol, 0); }
 void CenCC::buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol) { build(lImg, rImg, maxDis, rCostVol, 1); }
 
-// ---------------------------------------------------------------- PreSSPC / PreCSPC
+// ---------------------------------------------------------------- DeviceSlot, PreSSPC / PreCSPC / GrdPC / CSPC
 int DevicePlaneCost::device = 0;
 bool DevicePlaneCost::keep_context = false;
-cspm_ctx *DevicePlaneCost::kept_ctx_ = NULL;
-int DevicePlaneCost::kept_device_ = -1;
-std::vector<cspm_ctx *> DevicePlaneCost::live_;
 
-void DevicePlaneCost::adopt(cspm_ctx *ctx) { live_.push_back(ctx); }
-void DevicePlaneCost::disown(cspm_ctx *ctx) {
-  for (size_t i = 0; i < live_.size(); ++i)
-    if (live_[i] == ctx) { live_.erase(live_.begin() + i); return; }
+namespace {
+// the only process-wide state of the host layer: the registry of live contexts and the default slot, both behind one mutex
+std::mutex g_host_mutex;
+std::vector<cspm_ctx *> g_live;
+thread_local DeviceSlot *t_slot = NULL;
+DeviceSlot &default_slot() {
+  static DeviceSlot slot;
+  return slot;
 }
-bool DevicePlaneCost::is_live(const cspm_ctx *ctx) {
-  for (size_t i = 0; i < live_.size(); ++i)
-    if (live_[i] == ctx) return true;
-  return false;
-}
-
-static void forget(std::vector<cspm_ctx *> &v, cspm_ctx *c) {
+void forget(std::vector<cspm_ctx *> &v, const cspm_ctx *c) {
   for (size_t i = 0; i < v.size(); ++i)
     if (v[i] == c) { v.erase(v.begin() + i); return; }
 }
-
-void DevicePlaneCost::release_kept_context() {
-  if (kept_ctx_) { forget(live_, kept_ctx_); cspm_destroy(kept_ctx_); }
-  kept_ctx_ = NULL;
-  kept_device_ = -1;
+long long option(cspm_ctx *ctx, int key) {
+  long long v = 0;
+  return cspm_get_option(ctx, key, &v) == CSPM_OK ? v : 0;
 }
+}  // namespace
+
+DeviceSlot::Use::Use(DeviceSlot &slot) : prev_(t_slot) { t_slot = &slot; }
+DeviceSlot::Use::~Use() { t_slot = prev_; }
+
+int DeviceSlot::device_count() { return cspm_device_count(); }
+
+DeviceSlot &DeviceSlot::current() {
+  if (t_slot) return *t_slot;
+  DeviceSlot &d = default_slot();
+  cspm_ctx *stale = NULL;
+  {
+    std::lock_guard<std::mutex> lock(g_host_mutex);  // the default slot follows the statics (the reference-shaped, single-threaded flow)
+    if (d.device_ != DevicePlaneCost::device && d.parked_) { stale = d.parked_; d.parked_ = NULL; forget(g_live, stale); }
+    d.device_ = DevicePlaneCost::device;
+    d.keep_ = DevicePlaneCost::keep_context;
+  }
+  if (stale) cspm_destroy(stale);
+  return d;
+}
+
+cspm_ctx *DeviceSlot::take() {
+  std::lock_guard<std::mutex> lock(g_host_mutex);
+  cspm_ctx *c = parked_;
+  parked_ = NULL;
+  return c;
+}
+bool DeviceSlot::park(cspm_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_host_mutex);
+  if (!keep_ || parked_) return false;
+  parked_ = ctx;
+  return true;
+}
+void DeviceSlot::release() {
+  cspm_ctx *c = take();
+  if (!c) return;
+  DevicePlaneCost::disown(c);
+  cspm_destroy(c);
+}
+
+void DevicePlaneCost::adopt(cspm_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_host_mutex);
+  g_live.push_back(ctx);
+}
+void DevicePlaneCost::disown(cspm_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_host_mutex);
+  forget(g_live, ctx);
+}
+bool DevicePlaneCost::is_live(const cspm_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_host_mutex);
+  for (size_t i = 0; i < g_live.size(); ++i)
+    if (g_live[i] == ctx) return true;
+  return false;
+}
+void DevicePlaneCost::release_kept_context() { default_slot().release(); }
 
 void DevicePlaneCost::open_context(const Mat &l_img, const Mat &r_img) {
   CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // pre_cs_pc.cc:25, pre_ss_pc.cc:24, grd_pc.cc:22, cspc.cc:24
   CV_Assert(l_img.rows == r_img.rows && l_img.cols == r_img.cols);
-  if (kept_ctx_ && kept_device_ == device) {
-    ctx_ = kept_ctx_;
-    kept_ctx_ = NULL;
-  } else {
-    check(cspm_create(&ctx_, device), NULL, "cspm_create");
-    live_.push_back(ctx_);
+  if (!slot_) slot_ = &DeviceSlot::current();
+  ctx_ = slot_->take();
+  if (!ctx_) {
+    check(cspm_create(&ctx_, slot_->device()), NULL, "cspm_create");
+    adopt(ctx_);
+    if (slot_->sweep_wg() > 0) check(cspm_set_option(ctx_, CSPM_OPT_SWEEP_WG, slot_->sweep_wg()), ctx_, "cspm_set_option");
   }
+  base_sweep_fallbacks_ = option(ctx_, CSPM_OPT_SWEEP_FALLBACKS);
+  base_volume_fallbacks_ = option(ctx_, CSPM_OPT_VOLUME_FALLBACKS);
   const Mat l = l_img.clone(), r = r_img.clone();  // packed rows
   check(cspm_set_images(ctx_, l.data, r.data, l.cols, l.rows, l.step), ctx_, "cspm_set_images");
 }
 
+// a constructor that throws never runs the destructor: hand the context back (or destroy it) before the exception leaves
+#define CSPM_CTOR_GUARD(body)        \
+  try {                              \
+    body                             \
+  } catch (...) {                    \
+    close_context();                 \
+    throw;                           \
+  }
+
+void DevicePlaneCost::close_context() {
+  if (!ctx_) return;
+  if (slot_) {
+    slot_->sweep_fallbacks_ += option(ctx_, CSPM_OPT_SWEEP_FALLBACKS) - base_sweep_fallbacks_;
+    slot_->volume_fallbacks_ += option(ctx_, CSPM_OPT_VOLUME_FALLBACKS) - base_volume_fallbacks_;
+  }
+  if (!(slot_ && slot_->park(ctx_))) {
+    disown(ctx_);
+    cspm_destroy(ctx_);
+  }
+  ctx_ = NULL;
+}
+
 // GrdPC / CSPC
-DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, double reg_lambda)
-    : ctx_(NULL), ctx_device_(device) {
-  open_context(l_img, r_img);
-  check(cspm_build_cost_img(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_img");
+DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num, double reg_lambda, DeviceSlot *slot)
+    : ctx_(NULL), slot_(slot), base_sweep_fallbacks_(0), base_volume_fallbacks_(0) {
+  CSPM_CTOR_GUARD(
+    open_context(l_img, r_img);
+    check(cspm_build_cost_img(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_img");
+  )
 }
 
 DevicePlaneCost::DevicePlaneCost(const Mat &l_img, const Mat &r_img, int max_disp, int wnd_size, int scale_num,
-                                 CCMethod *cc_method, double reg_lambda)
-    : ctx_(NULL), ctx_device_(device) {
+                                 CCMethod *cc_method, double reg_lambda, DeviceSlot *slot)
+    : ctx_(NULL), slot_(slot), base_sweep_fallbacks_(0), base_volume_fallbacks_(0) {
   if (!cc_method) throw std::runtime_error("PreSSPC/PreCSPC: NULL CCMethod (unknown --cc_name)");  // the reference dereferences it
-  open_context(l_img, r_img);
-  if (dynamic_cast<GrdCC *>(cc_method)) {
-    // the known cost function: pyramid, gradients, max_cost, scale weights all on the device
-    check(cspm_build_cost_grd(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_grd");
-    return;
-  }
-  if (dynamic_cast<CenCC *>(cc_method)) {
-    check(cspm_build_cost_cen(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_cen");
-    return;
-  }
-  // a foreign CCMethod: let it fill host volumes level by level exactly as pre_cs_pc.cc:57-74 does
-  check(cspm_begin_cost(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_begin_cost");
-  const int levels = cspm_get_levels(ctx_);
-  for (int s = 0; s < levels; ++s)
-    for (int v = 0; v < kViewNum; ++v) upload_foreign(cc_method, v, s);
-  check(cspm_finish_cost(ctx_), ctx_, "cspm_finish_cost");
+  CSPM_CTOR_GUARD(
+    open_context(l_img, r_img);
+    if (dynamic_cast<GrdCC *>(cc_method)) {
+      // the known cost function: pyramid, gradients, max_cost, scale weights all on the device
+      check(cspm_build_cost_grd(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_grd");
+    } else if (dynamic_cast<CenCC *>(cc_method)) {
+      check(cspm_build_cost_cen(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_build_cost_cen");
+    } else {
+      // a foreign CCMethod: let it fill host volumes level by level exactly as pre_cs_pc.cc:57-74 does
+      check(cspm_begin_cost(ctx_, max_disp, wnd_size, scale_num, reg_lambda), ctx_, "cspm_begin_cost");
+      const int levels = cspm_get_levels(ctx_);
+      for (int s = 0; s < levels; ++s)
+        for (int v = 0; v < kViewNum; ++v) upload_foreign(cc_method, v, s);
+      check(cspm_finish_cost(ctx_), ctx_, "cspm_finish_cost");
+    }
+  )
 }
 
 void DevicePlaneCost::upload_foreign(CCMethod *cc, int view, int level) {
@@ -146,15 +221,7 @@ void DevicePlaneCost::upload_foreign(CCMethod *cc, int view, int level) {
     check(cspm_upload_cost_slab(ctx_, view, level, d, vol[d].ptr<double>(0), vol[d].step / sizeof(double)), ctx_, "cspm_upload_cost_slab");
 }
 
-DevicePlaneCost::~DevicePlaneCost() {
-  if (keep_context && !kept_ctx_ && ctx_) {
-    kept_ctx_ = ctx_;
-    kept_device_ = ctx_device_;
-  } else {
-    forget(live_, ctx_);
-    cspm_destroy(ctx_);
-  }
-}
+DevicePlaneCost::~DevicePlaneCost() { close_context(); }
 
 double DevicePlaneCost::GetPlaneCost(const int &ref_x, const int &ref_y, const Plane &plane, const RefView &view) const {
   const int xy[2] = {ref_x, ref_y};
@@ -182,7 +249,7 @@ CSPatchMatch::CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_di
 // (the reference calls it from OpenMP threads): the batches are evaluated in parallel when this file is built with -fopenmp.
 void CSPatchMatch::PatchMatchForeign(int iter_num, const IPlaneCost *plane_cost, bool use_pp) {
   if (!own_ctx_) {
-    check(cspm_create(&own_ctx_, DevicePlaneCost::device), NULL, "cspm_create");
+    check(cspm_create(&own_ctx_, DeviceSlot::current().device()), NULL, "cspm_create");  // the calling thread's GPU
     DevicePlaneCost::adopt(own_ctx_);
   }
   cspm_ctx *ctx = own_ctx_;

@@ -10,9 +10,12 @@
 #include "plane_cost/pre_ss_pc.h"
 #include "pfm_io.h"
 
+#include <atomic>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
 
 // images
 DEFINE_string(l_img_file, "l_img.png", "left input image (8-bit PNG / PPM / PGM)");
@@ -39,6 +42,11 @@ DEFINE_string(r_disp_pfm, "", "also write the right sub-pixel disparity map as f
 DEFINE_string(batch_list, "", "text file, one stereo pair per line: l_img r_img l_dis r_dis [l_pfm r_pfm]; all pairs run with the "
                               "matching flags of this command line on one device context (buffers are reused between pairs). A pair "
                               "that fails is reported and the batch goes on; the exit code is non-zero if any pair failed");
+DEFINE_int32(in_flight, 3, "with --batch_list: stereo pairs in flight per GPU.  Each is a worker thread with its own device context (one HIP stream): "
+                           "it decodes its pair's PNGs, runs it and encodes the maps while the other workers' kernels keep the GPU busy (the raster "
+                           "sweep of one pair leaves most CUs idle).  With 3 or more the sweep runs one workgroup per CU (CSPM_OPT_SWEEP_WG)");
+DEFINE_string(devices, "", "with --batch_list: GPUs to spread the pairs over: a comma-separated list of indices (an index may repeat: that many "
+                           "worker sets on that GPU) or `all`; empty = --device.  Pairs are independent: no data moves between GPUs");
 DEFINE_bool(batch_skip_existing, false, "with --batch_list: skip the pairs whose output maps already exist (restart an interrupted batch)");
 DEFINE_bool(quiet, false, "print errors and the batch summary only");
 
@@ -50,12 +58,13 @@ struct PairFiles {
   string l_img, r_img, l_dis, r_dis, l_pfm, r_pfm;
 };
 
-// one stereo pair: the flow of main.cc:57-139
-int run_pair(const PairFiles &f, CCMethod *cost_fn) {
+// one stereo pair: the flow of main.cc:57-139, on the calling thread's device slot.  `log` collects what the reference prints
+// (a batch worker's lines are written out in one piece when its pair is done).
+int run_pair(const PairFiles &f, CCMethod *cost_fn, std::ostream &log) {
   const Mat left = imread(f.l_img, CV_LOAD_IMAGE_COLOR), right = imread(f.r_img, CV_LOAD_IMAGE_COLOR);
   if (left.empty() || right.empty()) {
     // the reference waits for a key press here (main.cc:70-75); a batch tool must not
-    cout << "Error: can not open image\n";
+    log << "Error: can not open image\n";
     return EXIT_FAILURE;
   }
   const double t0 = static_cast<double>(getTickCount());
@@ -74,9 +83,9 @@ int run_pair(const PairFiles &f, CCMethod *cost_fn) {
   matcher.PatchMatch(FLAGS_iters, plane_cost, FLAGS_use_pp);
   const double seconds = (static_cast<double>(getTickCount()) - t0) / getTickFrequency();
   if (!FLAGS_quiet)
-    cout << "--------------------------------------------------------\n"
-         << "Total Time: " << seconds << "\n"
-         << "--------------------------------------------------------\n";
+    log << "--------------------------------------------------------\n"
+        << "Total Time: " << seconds << "\n"
+        << "--------------------------------------------------------\n";
   bool written = imwrite(f.l_dis, matcher.dis(kLeft)) && imwrite(f.r_dis, matcher.dis(kRight));
   const string *pfm[2] = {&f.l_pfm, &f.r_pfm};
   for (int v = 0; v < kViewNum && written; ++v) {
@@ -86,72 +95,144 @@ int run_pair(const PairFiles &f, CCMethod *cost_fn) {
     written = WritePFM(*pfm[v], d.data(), left.cols, left.rows);
   }
   if (!written) {
-    cout << "Error: can not write disparity maps\n";
+    log << "Error: can not write disparity maps\n";
     return EXIT_FAILURE;
   }
   return EXIT_SUCCESS;
 }
 
+struct BatchJob {
+  PairFiles files;
+  int line_no;
+};
+
+// --devices: "" -> {--device}; "all" -> every GPU; "0,1,1" -> those indices (repeats allowed).  Empty result = bad flag.
+std::vector<int> parse_devices() {
+  std::vector<int> out;
+  if (FLAGS_devices.empty()) {
+    out.push_back(FLAGS_device);
+    return out;
+  }
+  const int n = DeviceSlot::device_count();
+  if (FLAGS_devices == "all") {
+    for (int d = 0; d < n; ++d) out.push_back(d);
+    return out;
+  }
+  std::istringstream is(FLAGS_devices);
+  string tok;
+  while (std::getline(is, tok, ',')) {
+    char *end = NULL;
+    const long d = std::strtol(tok.c_str(), &end, 10);
+    if (tok.empty() || *end || d < 0 || d >= n) return std::vector<int>();
+    out.push_back(static_cast<int>(d));
+  }
+  return out;
+}
+
+// The batch: pairs are independent units.  One worker thread per (entry of --devices, slot of --in_flight), each with
+// its own DeviceSlot -- GPU index, parked context whose buffers the next pair of the worker takes over, sweep workgroups per CU -- and
+// its own CCMethod object; the workers pull pairs from one queue.  A worker blocks on its own pair only (cspm_ctx = one HIP stream), so
+// file decoding / encoding and the serial phases of one pair overlap with the kernels of the others.  Results do not depend on the
+// worker or GPU a pair lands on (same seed, same kernels): the maps equal the one-pair-at-a-time run bit for bit.
+int run_batch(const std::vector<BatchJob> &jobs, int skipped, int bad_lines) {
+  const std::vector<int> devices = parse_devices();
+  if (devices.empty()) {
+    cout << "Error: --devices must be `all` or a comma-separated list of GPU indices below " << DeviceSlot::device_count() << "\n";
+    return EXIT_FAILURE;
+  }
+  const int per_gpu = std::max(1, FLAGS_in_flight);
+  std::vector<int> on_gpu(DeviceSlot::device_count() > 0 ? DeviceSlot::device_count() : 1, 0);  // pairs in flight per physical GPU
+  for (size_t i = 0; i < devices.size(); ++i) on_gpu[devices[i]] += per_gpu;
+  std::atomic<size_t> next(0);
+  std::atomic<int> failed(bad_lines), done(0);
+  std::atomic<long long> sweep_fallbacks(0), volume_fallbacks(0);
+  std::mutex out_mutex;
+  const double t0 = static_cast<double>(getTickCount());
+  auto worker = [&](int device) {
+    DeviceSlot slot(device, /*keep_context=*/true, /*sweep_wg=*/on_gpu[device] >= 3 ? 1 : 0);
+    DeviceSlot::Use use(slot);
+    const std::unique_ptr<CCMethod> cost_fn(GetCCType(FLAGS_cc_name));  // NULL for unknown names, rejected by the cost constructors
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= jobs.size()) break;
+      const BatchJob &job = jobs[k];
+      std::ostringstream log;
+      if (!FLAGS_quiet) log << "Load Image: " << job.files.l_img << " " << job.files.r_img << "\n";
+      int pair_rc = EXIT_FAILURE;
+      try {
+        pair_rc = run_pair(job.files, cost_fn.get(), log);
+      } catch (const std::exception &e) {  // a bad pair must not take the batch down
+        log << "Error: " << e.what() << "\n";
+      }
+      if (pair_rc != EXIT_SUCCESS) {
+        ++failed;
+        log << "Pair FAILED (line " << job.line_no << "): " << job.files.l_img << " " << job.files.r_img << "\n";
+      }
+      ++done;
+      std::lock_guard<std::mutex> lock(out_mutex);
+      cout << log.str() << std::flush;
+    }
+    slot.release();
+    sweep_fallbacks += slot.sweep_fallbacks();
+    volume_fallbacks += slot.volume_fallbacks();
+  };
+  std::vector<std::thread> threads;
+  const size_t want = devices.size() * static_cast<size_t>(per_gpu);
+  for (size_t t = 0; t < std::min(want, std::max<size_t>(jobs.size(), 1)); ++t) threads.emplace_back(worker, devices[t % devices.size()]);
+  for (size_t t = 0; t < threads.size(); ++t) threads[t].join();
+  const double seconds = (static_cast<double>(getTickCount()) - t0) / getTickFrequency();
+  cout << "Batch: " << done.load() + bad_lines << " pairs in " << seconds << " s, " << failed.load() << " failed, " << skipped << " skipped\n";
+  if (!FLAGS_quiet) {
+    cout << "Batch workers: " << threads.size() << " (" << devices.size() << " GPU entr" << (devices.size() == 1 ? "y" : "ies") << " x " << per_gpu
+         << " in flight), " << (done.load() ? seconds * 1e3 / done.load() : 0.0) << " ms per pair end to end, files included\n";
+    cout << "Batch fallbacks: " << sweep_fallbacks.load() << " raster sweeps repeated after a hand-over timeout, " << volume_fallbacks.load()
+         << " optional volumes given up\n";
+  }
+  return failed.load() ? EXIT_FAILURE : EXIT_SUCCESS;
+}
+
 int run() {
   DevicePlaneCost::device = FLAGS_device;
-  CCMethod *cost_fn = GetCCType(FLAGS_cc_name);  // NULL for unknown names, rejected by the cost constructors
-  int rc = EXIT_SUCCESS;
   if (FLAGS_use_pp && !(FLAGS_l_disp_pfm.empty() && FLAGS_r_disp_pfm.empty()) && !FLAGS_quiet)
     cout << "Note: the PFM maps hold the plane disparities before post-processing\n";
   if (FLAGS_batch_list.empty()) {
+    const std::unique_ptr<CCMethod> cost_fn(GetCCType(FLAGS_cc_name));  // NULL for unknown names, rejected by the cost constructors
     if (!FLAGS_quiet) cout << "Load Image: " << FLAGS_l_img_file << " " << FLAGS_r_img_file << "\n";
-    rc = run_pair(PairFiles{FLAGS_l_img_file, FLAGS_r_img_file, FLAGS_l_dis_file, FLAGS_r_dis_file, FLAGS_l_disp_pfm, FLAGS_r_disp_pfm}, cost_fn);
-  } else {
-    std::ifstream list(FLAGS_batch_list.c_str());
-    if (!list) {
-      cout << "Error: can not open batch list " << FLAGS_batch_list << "\n";
-      delete cost_fn;
-      return EXIT_FAILURE;
-    }
-    DevicePlaneCost::keep_context = true;  // the next pair's PreSSPC / PreCSPC takes over the device buffers of the last
-    const double t0 = static_cast<double>(getTickCount());
-    string line;
-    int pairs = 0, failed = 0, skipped = 0, line_no = 0;
-    while (std::getline(list, line)) {
-      ++line_no;
-      std::istringstream is(line);
-      PairFiles f;
-      if (!(is >> f.l_img)) continue;  // blank line
-      if (f.l_img[0] == '#') continue;
-      if (!(is >> f.r_img >> f.l_dis >> f.r_dis)) {
-        cout << "Error: batch list line " << line_no << " needs l_img r_img l_dis r_dis: " << line << "\n";
-        ++failed;
-        continue;
-      }
-      is >> f.l_pfm >> f.r_pfm;
-      if (FLAGS_batch_skip_existing && std::ifstream(f.l_dis.c_str()).good() && std::ifstream(f.r_dis.c_str()).good()) {
-        ++skipped;
-        continue;
-      }
-      if (!FLAGS_quiet) cout << "Load Image: " << f.l_img << " " << f.r_img << "\n";
-      int pair_rc = EXIT_FAILURE;
-      try {
-        pair_rc = run_pair(f, cost_fn);
-      } catch (const std::exception &e) {  // a bad pair must not take the batch down
-        cout << "Error: " << e.what() << "\n";
-      }
-      ++pairs;
-      if (pair_rc != EXIT_SUCCESS) {
-        ++failed;
-        cout << "Pair FAILED (line " << line_no << "): " << f.l_img << " " << f.r_img << "\n";
-      }
-    }
-    const double seconds = (static_cast<double>(getTickCount()) - t0) / getTickFrequency();
-    cout << "Batch: " << pairs << " pairs in " << seconds << " s, " << failed << " failed, " << skipped << " skipped\n";
-    if (failed) rc = EXIT_FAILURE;
-    DevicePlaneCost::release_kept_context();
+    return run_pair(PairFiles{FLAGS_l_img_file, FLAGS_r_img_file, FLAGS_l_dis_file, FLAGS_r_dis_file, FLAGS_l_disp_pfm, FLAGS_r_disp_pfm}, cost_fn.get(), cout);
   }
-  delete cost_fn;
-  return rc;
+  std::ifstream list(FLAGS_batch_list.c_str());
+  if (!list) {
+    cout << "Error: can not open batch list " << FLAGS_batch_list << "\n";
+    return EXIT_FAILURE;
+  }
+  std::vector<BatchJob> jobs;
+  string line;
+  int bad_lines = 0, skipped = 0, line_no = 0;
+  while (std::getline(list, line)) {
+    ++line_no;
+    std::istringstream is(line);
+    PairFiles f;
+    if (!(is >> f.l_img)) continue;  // blank line
+    if (f.l_img[0] == '#') continue;
+    if (!(is >> f.r_img >> f.l_dis >> f.r_dis)) {
+      cout << "Error: batch list line " << line_no << " needs l_img r_img l_dis r_dis: " << line << "\n";
+      ++bad_lines;
+      continue;
+    }
+    is >> f.l_pfm >> f.r_pfm;
+    if (FLAGS_batch_skip_existing && std::ifstream(f.l_dis.c_str()).good() && std::ifstream(f.r_dis.c_str()).good()) {
+      ++skipped;
+      continue;
+    }
+    jobs.push_back(BatchJob{f, line_no});
+  }
+  return run_batch(jobs, skipped, bad_lines);
 }
 }  // namespace
 
 int main(int argc, char **argv) {
+  // HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; two pair streams that share a queue run one after the other
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   gflags::ParseCommandLineFlags(&argc, &argv, true);
   if (!FLAGS_quiet) cout << "PatchMatch Stereo Matching (MI355X)" << endl;
   try {

@@ -126,7 +126,8 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * Measured on MI355X: 8 % SLOWER (65.3 against 60.5 ms of sweeps per KITTI-size pair) although the microbenchmark confirms the L1 path
  * does a third less work -- the sweep is bound by the latency of its dependent steps, and unpacking adds instructions to each: off.
  * CSPM_OPT_SWEEP_PACKED_ACTIVE (read only): 1 when the current cost object carries the packed pixels.
- * CSPM_OPT_SWEEP_PACKED_BAD (read only; synchronises): pixels the packer could not represent exactly -- 0 by construction. */
+ * CSPM_OPT_SWEEP_PACKED_BAD (read only; synchronises): pixels the packer could not represent exactly -- 0 by construction; counted per
+ * cost object, and a non-zero count fails the next synchronising call with CSPM_ERR_HIP (the sweep would have read wrong cells). */
 /* CSPM_OPT_SWEEP_FLOW (default 0; measured on MI355X: 1 is 35 % slower, 26.9 against 20.0 ms per sweep of a KITTI-size pair): how the
  * persistent raster sweep (CSPM_OPT_RASTER_LAUNCHES = 0) hands out its pixels.  1 = by dataflow:
  * every pixel counts its final predecessors and the workgroup that completes the count continues with it at once (the other ready
@@ -138,6 +139,12 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * GPU (contexts on separate streams) should set 1: the sweep's workgroups hold registers and LDS that the other pairs' throughput kernels
  * would use -- measured with 3 pairs in flight: 146.5 ms per pair with 1, 150.6 with 2, 152.1 with 3. */
 #define CSPM_OPT_SWEEP_WG 14
+/* CSPM_OPT_VOLUME_RETRY_PAIRS (default 16; 0 = never): a cost object that wanted optional volumes and runs without them (free-memory veto
+ * or a failed hipMalloc, see CSPM_OPT_TABLE_VOLUMES) asks for them again after this many pairs have reused it.
+ * CSPM_OPT_FAULT_VOLUME_ALLOC (write only, TEST HOOK): the n-th optional-volume allocation of this context from now on fails as if
+ * hipMalloc had returned out-of-memory; a set_option call, never the environment, so that no deployment can switch it on by accident. */
+#define CSPM_OPT_VOLUME_RETRY_PAIRS 15
+#define CSPM_OPT_FAULT_VOLUME_ALLOC 16
 #define CSPM_OPT_SWEEP_PACKED 10
 #define CSPM_OPT_SWEEP_PACKED_ACTIVE 11
 #define CSPM_OPT_SWEEP_PACKED_BAD 12

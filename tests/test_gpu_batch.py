@@ -141,8 +141,10 @@ def test_run_batch_200_pairs_bounded_pinning(gpu_ctx):
 
 def test_table_volumes_are_optional_memory(gpu_ctx, tmp_path):
     """The device-cell volumes are an accelerator, not a requirement (advisor, round 4): a context whose share of the free memory
-    does not cover them, and one whose hipMalloc for them FAILS (fault injection), both go on with computed tables and produce
-    the same planes; the environment knob CSPM_TABLE_VOLUMES=0 is not overridden by the Python wrapper's defaults."""
+    does not cover them, and one whose hipMalloc for them FAILS (fault injection: CSPM_OPT_FAULT_VOLUME_ALLOC, a set_option test hook
+    that nothing in the environment reaches), both go on with computed tables and produce the same planes; the environment knob
+    CSPM_TABLE_VOLUMES=0 is not overridden by the Python wrapper's defaults.  A cost object that runs without the volumes it wanted
+    asks again after CSPM_OPT_VOLUME_RETRY_PAIRS reuses (advisor, round 5: one transient shortage must not last for ever)."""
     import crossscalepatchmatch_amd as cs
     from crossscalepatchmatch_amd import capi
     l, r = _pairs(1)[0]
@@ -151,7 +153,15 @@ def test_table_volumes_are_optional_memory(gpu_ctx, tmp_path):
     assert gpu_ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 1
     gpu_ctx.patchmatch(2, seed=4, schedule=0)
     want = [gpu_ctx.get_planes(v) for v in (0, 1)]
-    for env, fallbacks in (({"CSPM_VOLUMES_MEM_FRACTION": "0"}, 0), ({"CSPM_FAULT_VOLUME_ALLOC": "3"}, 1), ({"CSPM_TABLE_VOLUMES": "0"}, 0)):
+
+    def same_planes(ctx, tag):
+        ctx.patchmatch(2, seed=4, schedule=0)
+        for v in (0, 1):
+            npar, cost = ctx.get_planes(v)
+            np.testing.assert_array_equal(npar, want[v][0], err_msg=tag)
+            np.testing.assert_array_equal(cost, want[v][1], err_msg=tag)
+
+    for env, fault, fallbacks, comes_back in (({"CSPM_VOLUMES_MEM_FRACTION": "0"}, 0, 0, False), ({}, 3, 1, True), ({"CSPM_TABLE_VOLUMES": "0"}, 0, 0, False)):
         os.environ.update(env)
         try:
             ctx = cs.StereoContext(0)
@@ -159,16 +169,21 @@ def test_table_volumes_are_optional_memory(gpu_ctx, tmp_path):
             for k in env:
                 del os.environ[k]
         try:
+            assert ctx.get_option(capi.OPT_VOLUME_RETRY_PAIRS) == 16
+            ctx.set_option(capi.OPT_VOLUME_RETRY_PAIRS, 3)
+            if fault:
+                ctx.set_option(capi.OPT_FAULT_VOLUME_ALLOC, fault)
             ctx.set_images(l, r)
             ctx.build_cost_grd(D, 35, 5, 0.3)
-            assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 0, env
-            assert ctx.get_option(capi.OPT_VOLUME_FALLBACKS) == fallbacks, env
-            ctx.patchmatch(2, seed=4, schedule=0)
-            for v in (0, 1):
-                npar, cost = ctx.get_planes(v)
-                np.testing.assert_array_equal(npar, want[v][0], err_msg=str(env))
-                np.testing.assert_array_equal(cost, want[v][1], err_msg=str(env))
-            ctx.build_cost_grd(D, 35, 5, 0.3)  # the next pair of the same shape reuses the buffers as they are: no retry, no error
+            assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 0, (env, fault)
+            assert ctx.get_option(capi.OPT_VOLUME_FALLBACKS) == fallbacks, (env, fault)
+            same_planes(ctx, str((env, fault)))
+            for _ in range(2):  # the next pairs of the same shape reuse the buffers as they are: no retry yet, no error
+                ctx.build_cost_grd(D, 35, 5, 0.3)
+                assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == 0
+            ctx.build_cost_grd(D, 35, 5, 0.3)  # third reuse: asks again -- the injected failure was transient, a veto of the memory share is not
+            assert ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE) == (1 if comes_back else 0), (env, fault)
             assert ctx.get_option(capi.OPT_VOLUME_FALLBACKS) == fallbacks
+            same_planes(ctx, str((env, fault, "after the retry")))
         finally:
             ctx.close()
