@@ -16,6 +16,11 @@ class CSPatchMatch {
   // field, the random streams and the accept rules stay on the device (PatchMatchForeign).
   void PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp);
   Mat &dis(const RefView &view) { return dis_[view]; }
+  // PatchMatch in two halves for callers that overlap their own work (file decoding, the previous pair's encoding) with the GPU:
+  // Begin enqueues the whole loop on the cost object's stream and returns (a device cost; a foreign IPlaneCost runs to completion here),
+  // End waits for it and fills dis() -- PlaneToDisp, or PostProcessing when use_pp.  PatchMatch == Begin + End.
+  void PatchMatchBegin(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp);
+  void PatchMatchEnd();
 
   // additions (the reference seeds from time(NULL) and has one schedule)
   void set_seed(uint64_t seed) { seed_ = seed; }
@@ -34,6 +39,8 @@ class CSPatchMatch {
   int schedule_, rb_rounds_;
   cspm_ctx *last_ctx_;
   cspm_ctx *own_ctx_;  // foreign IPlaneCost: the context that holds the plane field
+  cspm_ctx *pending_ctx_;  // PatchMatchBegin without its PatchMatchEnd yet
+  bool pending_pp_;
   void PatchMatchForeign(int iter_num, const IPlaneCost *plane_cost, bool use_pp);
   CSPatchMatch(const CSPatchMatch &);
 };

@@ -234,7 +234,7 @@ double DevicePlaneCost::GetPlaneCost(const int &ref_x, const int &ref_y, const P
 
 // ---------------------------------------------------------------- CSPatchMatch (cs_patchmatch.cc:3-109)
 CSPatchMatch::CSPatchMatch(const Mat &l_img, const Mat &r_img, const int &max_dis, const int &dis_scale)
-    : max_dis_(max_dis), dis_scale_(dis_scale), seed_(12345), schedule_(CSPM_SCHED_RASTER), rb_rounds_(1), last_ctx_(NULL), own_ctx_(NULL) {
+    : max_dis_(max_dis), dis_scale_(dis_scale), seed_(12345), schedule_(CSPM_SCHED_RASTER), rb_rounds_(1), last_ctx_(NULL), own_ctx_(NULL), pending_ctx_(NULL), pending_pp_(false) {
   CV_Assert(l_img.type() == CV_8UC3 && r_img.type() == CV_8UC3);  // cs_patchmatch.cc:8
   img_[kLeft] = l_img.clone();
   img_[kRight] = r_img.clone();
@@ -305,7 +305,8 @@ CSPatchMatch::~CSPatchMatch() {
   }
 }
 
-void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp) {
+void CSPatchMatch::PatchMatchBegin(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp) {
+  if (pending_ctx_) throw std::runtime_error("CSPatchMatch::PatchMatchBegin: the previous run has not been ended");
   const IDevicePlaneCost *dev = dynamic_cast<const IDevicePlaneCost *>(plane_cost);
   if (!dev) {
     PatchMatchForeign(iter_num, plane_cost, use_pp);
@@ -317,14 +318,28 @@ void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost,
   p.seed = seed_;
   p.schedule = schedule_;
   p.rb_rounds = rb_rounds_;
-  check(cspm_patchmatch(ctx, iter_num, &p), ctx, "cspm_patchmatch");
-  if (use_pp) {  // PostProcessing (cs_patchmatch.cc:105-107)
+  check(cspm_patchmatch(ctx, iter_num, &p), ctx, "cspm_patchmatch");  // asynchronous: enqueued on the context's stream
+  pending_ctx_ = ctx;
+  pending_pp_ = use_pp;
+}
+
+void CSPatchMatch::PatchMatchEnd() {
+  cspm_ctx *ctx = pending_ctx_;
+  if (!ctx) return;  // nothing pending (a foreign IPlaneCost finished inside Begin)
+  pending_ctx_ = NULL;
+  if (!DevicePlaneCost::is_live(ctx)) throw std::runtime_error("CSPatchMatch::PatchMatchEnd: the plane cost the run was started on has been deleted");
+  if (pending_pp_) {  // PostProcessing (cs_patchmatch.cc:105-107)
     check(cspm_postprocess(ctx, dis_scale_, dis_[kLeft].data, dis_[kRight].data, dis_[kLeft].step), ctx, "cspm_postprocess");
-  } else {       // PlaneToDisp (cs_patchmatch.cc:103)
+  } else {            // PlaneToDisp (cs_patchmatch.cc:103)
     for (int v = 0; v < kViewNum; ++v)
       check(cspm_get_disparity_u8(ctx, v, dis_scale_, dis_[v].data, dis_[v].step), ctx, "cspm_get_disparity_u8");
   }
   last_ctx_ = ctx;
+}
+
+void CSPatchMatch::PatchMatch(const int &iter_num, const IPlaneCost *plane_cost, const bool &use_pp) {
+  PatchMatchBegin(iter_num, plane_cost, use_pp);
+  PatchMatchEnd();
 }
 
 void CSPatchMatch::disparity(const RefView &view, std::vector<double> *out) const {

@@ -58,47 +58,86 @@ struct PairFiles {
   string l_img, r_img, l_dis, r_dis, l_pfm, r_pfm;
 };
 
-// one stereo pair: the flow of main.cc:57-139, on the calling thread's device slot.  `log` collects what the reference prints
-// (a batch worker's lines are written out in one piece when its pair is done).
-int run_pair(const PairFiles &f, CCMethod *cost_fn, std::ostream &log) {
-  const Mat left = imread(f.l_img, CV_LOAD_IMAGE_COLOR), right = imread(f.r_img, CV_LOAD_IMAGE_COLOR);
-  if (left.empty() || right.empty()) {
+// One stereo pair on its way through the flow of main.cc:57-139, cut into the four stages a batch worker overlaps: load (decode the
+// files), begin (construct the plane cost, enqueue PatchMatch on the calling thread's device slot), finish (wait, fetch the maps,
+// release the cost object -- in batch mode its context is parked for the next pair), write (encode the maps).  `log` collects what the
+// reference prints (a batch worker's lines are written out in one piece when its pair is done).
+struct PairRun {
+  PairFiles files;
+  int line_no;
+  Mat left, right;
+  std::unique_ptr<IPlaneCost> cost;
+  std::unique_ptr<CSPatchMatch> matcher;
+  std::vector<double> pfm[kViewNum];
+  double t0;
+  int rc;
+  std::ostringstream log;
+  PairRun(const PairFiles &f, int line) : files(f), line_no(line), t0(0.0), rc(EXIT_SUCCESS) {}
+};
+
+void load(PairRun &p) {
+  p.left = imread(p.files.l_img, CV_LOAD_IMAGE_COLOR);
+  p.right = imread(p.files.r_img, CV_LOAD_IMAGE_COLOR);
+  if (p.left.empty() || p.right.empty()) {
     // the reference waits for a key press here (main.cc:70-75); a batch tool must not
-    log << "Error: can not open image\n";
-    return EXIT_FAILURE;
+    p.log << "Error: can not open image\n";
+    p.rc = EXIT_FAILURE;
   }
-  const double t0 = static_cast<double>(getTickCount());
-  IPlaneCost *plane_cost_raw;
-  if (FLAGS_pc_name == "IMG")
-    plane_cost_raw = FLAGS_use_cs ? static_cast<IPlaneCost *>(new CSPC(left, right, FLAGS_max_dis, kWindow, kScales, FLAGS_reg_lambda))
-                              : static_cast<IPlaneCost *>(new GrdPC(left, right, FLAGS_max_dis, kWindow));
-  else
-    plane_cost_raw = FLAGS_use_cs ? static_cast<IPlaneCost *>(new PreCSPC(left, right, FLAGS_max_dis, kWindow, kScales, cost_fn, FLAGS_reg_lambda))
-                                  : static_cast<IPlaneCost *>(new PreSSPC(left, right, FLAGS_max_dis, kWindow, cost_fn));
-  const std::unique_ptr<IPlaneCost> plane_cost_owner(plane_cost_raw);  // released on every path, exceptions included (batch mode goes on)
-  IPlaneCost *plane_cost = plane_cost_raw;
-  CSPatchMatch matcher(left, right, FLAGS_max_dis, FLAGS_dis_scale);
-  matcher.set_seed(static_cast<uint64_t>(FLAGS_seed));
-  matcher.set_schedule(FLAGS_schedule == "redblack" ? 1 : 0);
-  matcher.PatchMatch(FLAGS_iters, plane_cost, FLAGS_use_pp);
-  const double seconds = (static_cast<double>(getTickCount()) - t0) / getTickFrequency();
-  if (!FLAGS_quiet)
-    log << "--------------------------------------------------------\n"
-        << "Total Time: " << seconds << "\n"
-        << "--------------------------------------------------------\n";
-  bool written = imwrite(f.l_dis, matcher.dis(kLeft)) && imwrite(f.r_dis, matcher.dis(kRight));
-  const string *pfm[2] = {&f.l_pfm, &f.r_pfm};
-  for (int v = 0; v < kViewNum && written; ++v) {
-    if (pfm[v]->empty()) continue;
-    std::vector<double> d;
-    matcher.disparity(v == 0 ? kLeft : kRight, &d);
-    written = WritePFM(*pfm[v], d.data(), left.cols, left.rows);
+}
+
+void begin(PairRun &p, CCMethod *cost_fn) {
+  if (p.rc != EXIT_SUCCESS) return;
+  try {
+    p.t0 = static_cast<double>(getTickCount());
+    IPlaneCost *pc;
+    if (FLAGS_pc_name == "IMG")
+      pc = FLAGS_use_cs ? static_cast<IPlaneCost *>(new CSPC(p.left, p.right, FLAGS_max_dis, kWindow, kScales, FLAGS_reg_lambda))
+                        : static_cast<IPlaneCost *>(new GrdPC(p.left, p.right, FLAGS_max_dis, kWindow));
+    else
+      pc = FLAGS_use_cs ? static_cast<IPlaneCost *>(new PreCSPC(p.left, p.right, FLAGS_max_dis, kWindow, kScales, cost_fn, FLAGS_reg_lambda))
+                        : static_cast<IPlaneCost *>(new PreSSPC(p.left, p.right, FLAGS_max_dis, kWindow, cost_fn));
+    p.cost.reset(pc);  // released on every path, exceptions included (batch mode goes on)
+    p.matcher.reset(new CSPatchMatch(p.left, p.right, FLAGS_max_dis, FLAGS_dis_scale));
+    p.matcher->set_seed(static_cast<uint64_t>(FLAGS_seed));
+    p.matcher->set_schedule(FLAGS_schedule == "redblack" ? 1 : 0);
+    p.matcher->PatchMatchBegin(FLAGS_iters, p.cost.get(), FLAGS_use_pp);
+  } catch (const std::exception &e) {  // a bad pair must not take the batch down
+    p.log << "Error: " << e.what() << "\n";
+    p.rc = EXIT_FAILURE;
+    p.cost.reset();
   }
+}
+
+void finish(PairRun &p) {
+  if (p.rc == EXIT_SUCCESS) {
+    try {
+      p.matcher->PatchMatchEnd();
+      const double seconds = (static_cast<double>(getTickCount()) - p.t0) / getTickFrequency();
+      if (!FLAGS_quiet)
+        p.log << "--------------------------------------------------------\n"
+              << "Total Time: " << seconds << "\n"
+              << "--------------------------------------------------------\n";
+      const string *pfm[kViewNum] = {&p.files.l_pfm, &p.files.r_pfm};
+      for (int v = 0; v < kViewNum; ++v)
+        if (!pfm[v]->empty()) p.matcher->disparity(v == 0 ? kLeft : kRight, &p.pfm[v]);  // reads the cost object's context: before it goes
+    } catch (const std::exception &e) {
+      p.log << "Error: " << e.what() << "\n";
+      p.rc = EXIT_FAILURE;
+    }
+  }
+  p.cost.reset();
+}
+
+void write(PairRun &p) {
+  if (p.rc != EXIT_SUCCESS) return;
+  bool written = imwrite(p.files.l_dis, p.matcher->dis(kLeft)) && imwrite(p.files.r_dis, p.matcher->dis(kRight));
+  const string *pfm[kViewNum] = {&p.files.l_pfm, &p.files.r_pfm};
+  for (int v = 0; v < kViewNum && written; ++v)
+    if (!pfm[v]->empty()) written = WritePFM(*pfm[v], p.pfm[v].data(), p.left.cols, p.left.rows);
   if (!written) {
-    log << "Error: can not write disparity maps\n";
-    return EXIT_FAILURE;
+    p.log << "Error: can not write disparity maps\n";
+    p.rc = EXIT_FAILURE;
   }
-  return EXIT_SUCCESS;
 }
 
 struct BatchJob {
@@ -152,25 +191,39 @@ int run_batch(const std::vector<BatchJob> &jobs, int skipped, int bad_lines) {
     DeviceSlot slot(device, /*keep_context=*/true, /*sweep_wg=*/on_gpu[device] >= 3 ? 1 : 0);
     DeviceSlot::Use use(slot);
     const std::unique_ptr<CCMethod> cost_fn(GetCCType(FLAGS_cc_name));  // NULL for unknown names, rejected by the cost constructors
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= jobs.size()) break;
-      const BatchJob &job = jobs[k];
-      std::ostringstream log;
-      if (!FLAGS_quiet) log << "Load Image: " << job.files.l_img << " " << job.files.r_img << "\n";
-      int pair_rc = EXIT_FAILURE;
-      try {
-        pair_rc = run_pair(job.files, cost_fn.get(), log);
-      } catch (const std::exception &e) {  // a bad pair must not take the batch down
-        log << "Error: " << e.what() << "\n";
-      }
-      if (pair_rc != EXIT_SUCCESS) {
+    // the next pair of the queue, decoded; a pair whose files cannot be read is reported at once and the worker moves on
+    auto report = [&](PairRun &p) {
+      if (p.rc != EXIT_SUCCESS) {
         ++failed;
-        log << "Pair FAILED (line " << job.line_no << "): " << job.files.l_img << " " << job.files.r_img << "\n";
+        p.log << "Pair FAILED (line " << p.line_no << "): " << p.files.l_img << " " << p.files.r_img << "\n";
       }
       ++done;
       std::lock_guard<std::mutex> lock(out_mutex);
-      cout << log.str() << std::flush;
+      cout << p.log.str() << std::flush;
+    };
+    auto next_loaded = [&]() -> std::unique_ptr<PairRun> {
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= jobs.size()) return std::unique_ptr<PairRun>();
+        std::unique_ptr<PairRun> p(new PairRun(jobs[k].files, jobs[k].line_no));
+        if (!FLAGS_quiet) p->log << "Load Image: " << p->files.l_img << " " << p->files.r_img << "\n";
+        load(*p);
+        if (p->rc == EXIT_SUCCESS) return p;
+        report(*p);
+      }
+    };
+    // software pipeline: while pair k is on the GPU the worker decodes pair k+1; as soon as k's maps are on the host, k+1 is
+    // enqueued (on the context k just parked) and only then are k's maps encoded and written -- the worker's stream idles for the
+    // download and the upload only, not for the files
+    std::unique_ptr<PairRun> cur = next_loaded();
+    if (cur) begin(*cur, cost_fn.get());
+    while (cur) {
+      std::unique_ptr<PairRun> nxt = next_loaded();
+      finish(*cur);
+      if (nxt) begin(*nxt, cost_fn.get());
+      write(*cur);
+      report(*cur);
+      cur = std::move(nxt);
     }
     slot.release();
     sweep_fallbacks += slot.sweep_fallbacks();
@@ -198,7 +251,13 @@ int run() {
   if (FLAGS_batch_list.empty()) {
     const std::unique_ptr<CCMethod> cost_fn(GetCCType(FLAGS_cc_name));  // NULL for unknown names, rejected by the cost constructors
     if (!FLAGS_quiet) cout << "Load Image: " << FLAGS_l_img_file << " " << FLAGS_r_img_file << "\n";
-    return run_pair(PairFiles{FLAGS_l_img_file, FLAGS_r_img_file, FLAGS_l_dis_file, FLAGS_r_dis_file, FLAGS_l_disp_pfm, FLAGS_r_disp_pfm}, cost_fn.get(), cout);
+    PairRun p(PairFiles{FLAGS_l_img_file, FLAGS_r_img_file, FLAGS_l_dis_file, FLAGS_r_dis_file, FLAGS_l_disp_pfm, FLAGS_r_disp_pfm}, 0);
+    load(p);
+    begin(p, cost_fn.get());
+    finish(p);
+    write(p);
+    cout << p.log.str();
+    return p.rc;
   }
   std::ifstream list(FLAGS_batch_list.c_str());
   if (!list) {

@@ -55,12 +55,45 @@ l, r, _, _ = synth.make_pair(96, 64, 16, regions=3, seed=5)
 pngio.write_png("l.png", l[..., ::-1]); pngio.write_png("r.png", r[..., ::-1])
 open("list.txt", "w").write("l.png r.png ld1.png rd1.png l1.pfm r1.pfm\nnope_l.png nope_r.png x.png y.png\nl.png r.png ld2.png rd2.png\n")
 PY
-  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0
+  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:use_sigaltstack=0  # sigaltstack: ASan's per-thread alternate stack trips its own CHECK when a worker thread exits under the HIP runtime
   ./cspm_main_asan --l_img_file=l.png --r_img_file=r.png --l_dis_file=ld.png --r_dis_file=rd.png --max_dis=16 --dis_scale=4 --cc_name=GRD \
       --use_cs=true --use_pp=true --reg_lambda=0.3 --quiet
-  ./cspm_main_asan --batch_list=list.txt --max_dis=16 --dis_scale=4 --cc_name=GRD --use_cs=true --reg_lambda=0.3 --quiet && exit 1 || true
+  set +e
+  ./cspm_main_asan --batch_list=list.txt --in_flight=2 --max_dis=16 --dis_scale=4 --cc_name=GRD --use_cs=true --reg_lambda=0.3 --quiet > batch.out 2> batch.err
+  rc=$?
+  set -e
+  # exactly the "one pair failed" exit, the summary line, and nothing from a sanitizer (a crash must not pass for the expected failure)
+  [ "$rc" = 1 ] && grep -q "Batch: 3 pairs" batch.out && grep -q "1 failed" batch.out && ! grep -qE "Sanitizer|runtime error" batch.err || { cat batch.out batch.err | tail -40; exit 1; }
   cmp ld1.png ld2.png
   echo "asan/ubsan: command line on the GPU clean (single pair + batch list with a failing line)"
+  # (3) ThreadSanitizer over the worker-thread batch (round 6): host sources rebuilt with -fsanitize=thread, 8 pairs of two sizes
+  #     through --devices 0,0 --in_flight 2 (four workers: DeviceSlot, parked contexts, the live registry, the shared output stream).
+  #     The HIP runtime is not instrumented; a report counts only when one of its frames is in the host layer's own sources.
+  g++ -fsanitize=thread -fno-omit-frame-pointer -g -O1 -std=c++14 -pthread -I "$H" -o "$B/cspm_main_tsan" "$H/main.cc" "$H/host_impl.cc" "$H/image_io.cc" \
+      -L"$R/crossscalepatchmatch_amd" -lcspm_hip -lz -Wl,-rpath,"$R/crossscalepatchmatch_amd"
+  python3 - "$R" <<'PY'
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import pngio
+from crossscalepatchmatch_amd import synth
+lines = []
+for i in range(8):
+    w, h = ((96, 64), (64, 48))[i % 2]
+    l, r, _, _ = synth.make_pair(w, h, 16, regions=3, seed=40 + i)
+    pngio.write_png(f"tl{i}.png", l[..., ::-1]); pngio.write_png(f"tr{i}.png", r[..., ::-1])
+    lines.append(f"tl{i}.png tr{i}.png tld{i}.png trd{i}.png")
+open("tlist.txt", "w").write("\n".join(lines) + "\n")
+PY
+  # setarch -R: no address-space randomisation -- TSan refuses the high-entropy mmap layout of this kernel ("unexpected memory mapping")
+  export TSAN_OPTIONS="halt_on_error=0 exitcode=0 report_signal_unsafe=0 log_path=$B/tsan_report"
+  rm -f "$B"/tsan_report.*
+  setarch "$(uname -m)" -R ./cspm_main_tsan --batch_list=tlist.txt --devices=0,0 --in_flight=2 --max_dis=16 --dis_scale=4 --cc_name=GRD --use_cs=true --use_pp=true \
+      --reg_lambda=0.3 --quiet || { echo "tsan: the batch itself failed"; exit 1; }
+  if cat "$B"/tsan_report.* 2>/dev/null | grep -E "main\.cc|host_impl\.cc|image_io\.cc|device_plane_cost\.h|cv_compat\.h" >/dev/null; then
+    echo "tsan: a report names the host layer:"; cat "$B"/tsan_report.* | head -80; exit 1
+  fi
+  mkdir -p "$R/gpurun_out" && cat "$B"/tsan_report.* > "$R/gpurun_out/tsan_report.txt" 2>/dev/null || true
+  echo "tsan: worker-thread batch clean ($(cat "$B"/tsan_report.* 2>/dev/null | grep -c 'WARNING: ThreadSanitizer' || true) reports, none with a frame in the host layer)"
 else
   echo "asan/ubsan: no GPU (or libcspm_hip.so missing): the command-line step is skipped"
 fi
