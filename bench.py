@@ -135,6 +135,35 @@ def cpu_baseline(device_index=0, crop=0, extra_legs=True):
     return out
 
 
+def real_pair_accuracy(device_index=0):
+    """bad-2.0 against REAL ground truth (the synthetic pairs have none worth the name): the Middlebury-2014 Motorcycle pair shipped with
+    scikit-image in this image, left view, pixels with known ground truth -- the whole 741x500 pair (max_dis 64) and its half-size
+    version (370x250, max_dis 32: the size SURVEY.md 8(c) quotes the unmodified reference on) where that directory exists, and always
+    the 200x128 half-size crop committed under tests/data/.  GRD, 5 levels, lambda 0.3, 3 iterations, seed 12345, raw planes and
+    after post-processing.  Outside the timed region."""
+    import crossscalepatchmatch_amd as cs
+    from crossscalepatchmatch_amd import realdata as rd
+    out = {"reference_probe_half_size_raw": "0.109-0.111 (SURVEY.md 8(c): the unmodified reference, clock-seeded, 370x250 max_dis 32)",
+           "metric": "fraction of left-view pixels with known ground truth whose disparity is off by more than 2 px"}
+    g = cs.StereoContext(device_index)
+    try:
+        for name, loader in (("full_741x500_D64", rd.load_full), ("half_370x250_D32", rd.load_half), ("crop_200x128_D32", rd.load_crop)):
+            item = loader()
+            if item is None:
+                out[name] = None
+                continue
+            cfg, l, r, gt = item
+            g.set_images(l, r)
+            g.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+            g.patchmatch(3, seed=12345, schedule=cs.SCHED_RASTER)
+            raw = rd.bad_fraction(g.disparity_f64(0), gt, 2.0)
+            lo, _ = g.postprocess(cfg["dis_scale"])
+            out[name] = {"raw": raw, "post_processed": rd.bad_fraction(lo.astype(np.float64) / cfg["dis_scale"], gt, 2.0)}
+    finally:
+        g.close()
+    return out
+
+
 def main():
     # ONE JSON line on stdout, nothing else: native libraries write to file descriptor 1 behind Python's back (RCCL prints a
     # five-line version banner there when a communicator is created).  Keep the real stdout for the result line and point fd 1 at
@@ -166,6 +195,7 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=0, help="CPU baseline on a centred crop of this many columns of C3 (with the whole pair extrapolated and "
                                                             "labelled so) instead of the whole pair, which takes three to four minutes of host time")
     ap.add_argument("--cpu-c3-only", action="store_true", help="CPU baseline: skip the C2 and C1 legs")
+    ap.add_argument("--no-real-pair", action="store_true", help="skip the accuracy figure on the real Middlebury pair (real_pair_bad2)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket launches with hipEvents")
     args = ap.parse_args()
 
@@ -304,6 +334,7 @@ def main():
         ctx.synchronize()
         ctx.enable_timing(not args.no_kernel_timing)
         ctx.reset_timing()
+    fallbacks_before = (sum(ctx.get_option(capi.OPT_SWEEP_FALLBACKS) for ctx in ctxs), sum(ctx.get_option(capi.OPT_VOLUME_FALLBACKS) for ctx in ctxs))
     sync_all()
     t0 = time.perf_counter()
     if batch_mode:
@@ -317,6 +348,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # what happened inside the timed region, beyond its duration: a raster sweep that timed out and was repeated with per-diagonal
+    # launches, or an optional volume that could not be allocated, means `value` timed a different code path than the one it names
+    sweep_fallbacks = sum(ctx.get_option(capi.OPT_SWEEP_FALLBACKS) for ctx in ctxs) - fallbacks_before[0]
+    volume_fallbacks = sum(ctx.get_option(capi.OPT_VOLUME_FALLBACKS) for ctx in ctxs) - fallbacks_before[1]
+    table_volumes_active = [int(ctx.get_option(capi.OPT_TABLE_VOLUMES_ACTIVE)) for ctx in ctxs]
+    if dist is not None:  # every rank's contexts
+        fb = torch.tensor([sweep_fallbacks, volume_fallbacks], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
+        sweep_fallbacks, volume_fallbacks = int(fb[0].item()), int(fb[1].item())
     timing = {}
     for ctx in ctxs:
         for k, v in ctx.timing().items():
@@ -339,6 +379,7 @@ def main():
         ctxs[0].enable_timing(False)
         ctxs[0].set_option(capi.OPT_SWEEP_WG, wg_keep)
 
+    bad_run = False
     if rank == 0:
         ctx = ctxs[0]
         mpix = w * h * args.steps * world / dt / 1e6
@@ -447,8 +488,16 @@ def main():
                                         "valu_winstr_per_launch_pmc": spmc.get("valu_winstr_per_launch"), "vmem_rd_instr_per_pixel_pmc": spmc.get("vmem_rd_instr_per_launch", 0) / (2.0 * w * h),
                                         "traffic": spmc.get("hbm_bytes_per_launch"), "bound": "L1 return path (TD) + dependency chain of the anti-diagonals"})
             out["roofline"] = roof
-        out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}  # with pairs in flight: overlapping brackets
+        # hipEvent brackets of the launches, summed per kernel class and divided by the pairs.  With several pairs in flight the brackets
+        # of different pairs OVERLAP in time (a launch's bracket also contains whatever the other streams ran meanwhile), so these do not
+        # add up to ms_per_step and are not kernel durations: the key says so.  Durations: roofline.kernels / kernel_ms_one_pair_alone.
+        out["kernel_bracket_ms_per_pair_overlapping" if nfl > 1 else "kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in timing.items()}
         out["kernel_launches_per_step"] = {k: v["launches"] / args.steps for k, v in timing.items()}
+        out["sweep_fallbacks"] = int(sweep_fallbacks)
+        out["volume_fallbacks"] = int(volume_fallbacks)
+        out["table_volumes_active"] = bool(all(table_volumes_active)) if args.cc == "GRD" and not args.volumes else None
+        out["timed_region_note"] = ("sweep_fallbacks / volume_fallbacks: raster sweeps repeated with per-diagonal launches after a hand-over timeout, and "
+                                    "optional volumes given up, INSIDE the timed region (all contexts of all ranks); both must be 0 or the run exits non-zero")
         if nfl > 1:
             out["kernel_ms_one_pair_alone"] = {k: v["ms"] for k, v in solo.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
@@ -461,8 +510,12 @@ def main():
             last = ctxs[(args.steps - 1) % nfl]
             out["bad2_vs_gt_left"] = synth.bad_fraction(last.disparity_f64(0), gl, 2.0)
         out["distinct_pairs"] = npairs
+        if world == 1 and not args.no_real_pair:
+            out["real_pair_bad2"] = real_pair_accuracy(dev_index)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
+        if sweep_fallbacks or volume_fallbacks:
+            bad_run = True
     if pair_fn is not None:
         pair_fn.close()
     else:
@@ -470,6 +523,9 @@ def main():
             ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if bad_run:
+        raise SystemExit("bench.py: a fallback happened inside the timed region (sweep_fallbacks / volume_fallbacks in the JSON line): "
+                         "`value` timed another code path than the one the line names")
 
 
 if __name__ == "__main__":

@@ -107,7 +107,8 @@ struct cspm_ctx {
   bool field_consistent = false;  // every min_cost was computed from the stored plane by this cost object (not by cspm_set_planes)
   double *field_mem = nullptr;
   Field f[2]{};
-  ViewCand vc{nullptr, nullptr, nullptr};
+  ViewCand vc{nullptr, nullptr, nullptr, nullptr};
+  long long opt_view_sort = 1;  // CSPM_OPT_VIEW_SORT: view propagation evaluates a row's proposals in the order of their target column
   uint8_t *d_dis[2] = {nullptr, nullptr};
   uint8_t *d_valid[2] = {nullptr, nullptr};  // post-processing: left-right consistency flags
   unsigned int *d_todo = nullptr;            // post-processing: per view n indices of inconsistent pixels, then the two counts
@@ -227,18 +228,20 @@ int drain_timing(cspm_ctx *c) {
 // row engine: one wave per 64-pixel run of an image row, kRowWaves waves per workgroup, grid a multiple of 8 (XCD bands)
 // a row-kernel launch: claimed column bands when it runs for several rounds of resident waves, interleaved row blocks otherwise
 // (cspm_rows.h row_item); workgroups of kRowWaves waves, grid a multiple of 8
-inline bool row_claimed(const cspm_ctx *c, int views) {
-  const long long items = row_items(c->W, c->H, views);
+inline bool row_claimed_w(const cspm_ctx *c, int W, int views) {
+  const long long items = row_items(W, c->H, views);
   if (items >= (1LL << 31)) return false;
   if (c->row_claim >= 0) return c->row_claim != 0;
   return items >= 2LL * c->ncu * 12;  // two rounds of the 12 waves a CU holds (a KITTI-size pair: every row kernel; a 450 x 375 pair: none)
 }
-inline unsigned row_grid(const cspm_ctx *c, int views) {
-  const bool claimed = row_claimed(c, views);
-  long long per_xcd = (row_items_per_xcd(c->W, c->H, views, claimed) + kRowWaves - 1) / kRowWaves;
+inline unsigned row_grid_w(const cspm_ctx *c, int W, int views) {
+  const bool claimed = row_claimed_w(c, W, views);
+  long long per_xcd = (row_items_per_xcd(W, c->H, views, claimed) + kRowWaves - 1) / kRowWaves;
   if (claimed) per_xcd += per_xcd / 4 + 1;  // the surplus workgroups of the XCDs that finish first take over the others' bands
   return (unsigned)(per_xcd * 8);
 }
+inline bool row_claimed(const cspm_ctx *c, int views) { return row_claimed_w(c, c->W, views); }
+inline unsigned row_grid(const cspm_ctx *c, int views) { return row_grid_w(c, c->W, views); }
 inline int row_cap(const cspm_ctx *c) { return strip_capacity(c->max_dis, c->cost.half); }
 inline int row_ocap(const cspm_ctx *c) { return own_capacity(c->cost.half); }
 inline size_t row_shmem(const cspm_ctx *c) { return sizeof(LutMem) + (size_t)kRowWaves * wave_lds_bytes(row_cap(c), row_ocap(c)); }
@@ -272,6 +275,7 @@ void free_field(cspm_ctx *c) {
   if (c->vc.cost) (void)hipFree(c->vc.cost);
   if (c->vc.c) (void)hipFree(c->vc.c);
   if (c->vc.cx) (void)hipFree(c->vc.cx);
+  if (c->vc.perm) (void)hipFree(c->vc.perm);
   for (int v = 0; v < 2; ++v) {
     if (c->d_dis[v]) (void)hipFree(c->d_dis[v]);
     if (c->d_valid[v]) (void)hipFree(c->d_valid[v]);
@@ -300,7 +304,7 @@ void free_field(cspm_ctx *c) {
   c->d_sweep_ctrl = c->d_sweep_start = nullptr;
   c->d_sweep_gran = nullptr;
   c->field_mem = nullptr;
-  c->vc = ViewCand{nullptr, nullptr, nullptr};
+  c->vc = ViewCand{nullptr, nullptr, nullptr, nullptr};
   c->field_alloc = false;
 }
 void free_images(cspm_ctx *c) {
@@ -653,6 +657,7 @@ int ensure_field(cspm_ctx *c) {
   if ((rc = dalloc(c, &c->vc.cost, n, nullptr))) return rc;
   if ((rc = dalloc(c, &c->vc.c, n, nullptr))) return rc;
   if ((rc = dalloc(c, &c->vc.cx, n, nullptr))) return rc;
+  if ((rc = dalloc(c, &c->vc.perm, n, nullptr))) return rc;
   for (int v = 0; v < 2; ++v) {
     if ((rc = dalloc(c, &c->d_dis[v], n, nullptr))) return rc;
     if ((rc = dalloc(c, &c->d_valid[v], n, nullptr))) return rc;
@@ -925,11 +930,18 @@ int do_view(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   const long long items = (long long)c->W * c->H;
   const size_t shmem = (size_t)c->W * (sizeof(unsigned long long) + sizeof(unsigned int));
   if (shmem > 160 * 1024) return fail(c, CSPM_ERR_ARG, "image too wide for the view-propagation row resolver");
+  ViewCand vc = c->vc;
+  const size_t sort_shmem = (size_t)(c->W + 1 + 256) * sizeof(unsigned int);
+  if (!c->opt_view_sort || sort_shmem > 160 * 1024) vc.perm = nullptr;
   for (int v = 0; v < 2; ++v) {
+    if (vc.perm) {
+      Timed t(c, CSPM_K_MISC, 0);
+      LAUNCH_ONE(k_view_sort, dim3(c->H), dim3(256), sort_shmem, pm, v, vc);
+    }
     {
       Timed t(c, CSPM_K_VIEW, items);
       const RowQueue rq = next_row_queue(c, 1);
-      LAUNCH_CS(k_view_eval, dim3(row_grid(c, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, rq, v, c->vc, row_cap(c), row_ocap(c));
+      LAUNCH_CS(k_view_eval, dim3(row_grid(c, 1)), dim3(kRowBlock), row_shmem(c), c->cost, pm, rq, v, vc, row_cap(c), row_ocap(c));
     }
     {
       Timed t(c, CSPM_K_MISC, 0);
@@ -1054,6 +1066,7 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_TABLE_VOLUMES_MAX_MB")) c->table_volumes_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_PACKED")) c->opt_sweep_packed = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_SWEEP_FLOW")) c->opt_sweep_flow = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_VIEW_SORT")) c->opt_view_sort = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
@@ -1171,6 +1184,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_SWEEP_PACKED: c->opt_sweep_packed = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: c->opt_sweep_flow = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: c->sweep_wg_per_cu = value < 0 ? 0 : (value > 16 ? 16 : (int)value); return CSPM_OK;
+    case CSPM_OPT_VIEW_SORT: c->opt_view_sort = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_FAULT_VOLUME_ALLOC: c->fault_volume_alloc = value < 0 ? 0 : (int)value; return CSPM_OK;
     case CSPM_OPT_VOLUME_RETRY_PAIRS: c->volume_retry_pairs = value < 0 ? 0 : value; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
@@ -1194,6 +1208,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_SWEEP_PAIRS_ACTIVE: *value = c->sweep_pairs ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
     case CSPM_OPT_VOLUME_RETRY_PAIRS: *value = c->volume_retry_pairs; return CSPM_OK;
+    case CSPM_OPT_VIEW_SORT: *value = c->opt_view_sort; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: *value = c->opt_sweep_flow; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: *value = c->sweep_wg_per_cu; return CSPM_OK;

@@ -510,6 +510,9 @@ __global__ __launch_bounds__(kEvalBlock) void k_spatial_rb(Cost cd, Pm pm, int c
 // every tap is computed once).  Work split: cross-scale -> one wave per pyramid level; single-scale -> one wave per
 // chain pass.  No early exit: both candidate costs are needed in full when accepted.
 // ------------------------------------------------------------------------------------------------
+#ifndef CSPM_SWEEP_POLL_SLEEP
+#define CSPM_SWEEP_POLL_SLEEP 1  // s_sleep argument (x 64 cycles) between two polls of a predecessor's granules
+#endif
 #ifndef CSPM_SWEEP_PRIO
 #define CSPM_SWEEP_PRIO 3
 #endif
@@ -729,7 +732,7 @@ __device__ __forceinline__ bool wait_granules(const unsigned long long *p, bool 
     if (need) g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool ready = !need || (unsigned int)(g >> 32) == epoch;
     if (__builtin_amdgcn_ballot_w64(!ready) == 0ull) return true;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(CSPM_SWEEP_POLL_SLEEP);
     if ((spins & 255u) == 0u) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
       if (wall_clock64() - t0 > timeout_ticks) {  // CSPM_OPT_SWEEP_TIMEOUT_MS, default 3 s

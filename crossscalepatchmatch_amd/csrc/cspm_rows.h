@@ -1486,6 +1486,7 @@ struct ViewCand {
   double *cost; // candidate cost, +inf = rejected / none
   double *c;    // candidate param c (a, b follow from the source normal)
   int *cx;      // target column
+  int *perm;    // per row: the source columns ordered by TARGET column (k_view_sort); null: lanes take consecutive source columns
 };
 
 // the proposal of source pixel (x,y) of view 1-v: target column (may be outside the image) and the plane anchored there
@@ -1508,6 +1509,54 @@ __device__ __forceinline__ ViewProposal view_proposal(const Pm &pm, int v, int x
   return q;
 }
 
+// Round 6 -- lanes TARGET-adjacent instead of source-adjacent.  A wave of 64 consecutive SOURCE pixels whose disparities straddle a depth
+// edge proposes into two stretches of the target row that lie up to max_dis apart; its strips cannot cover both and the whole wave
+// falls back to global gathers (15-20 % of the level-0 window rows of a KITTI-size pair).  The resolve rule does not care who evaluated
+// a proposal (k_view_resolve: smallest cost, earliest traversal rank among equals), so the proposals of a row are handed to the lanes
+// in the order of their TARGET column: one workgroup per row counts the proposals per target column in LDS, scans, and writes the
+// permutation (proposals without a target inside the image last); wave k of the row takes slots [64k, 64k + 64).  Equal targets keep
+// no particular order -- every proposal is evaluated exactly once either way, by the same function of (source pixel, target pixel).
+// Measured (C3, profiles/r06_viewsort/): unstaged level-0 window rows -25 %, k_view_eval 2.08 -> 1.87 ms per launch.  Cutting the
+// order into runs whose targets span at most 64 columns (every run staged, no unstaged row left) was built too and is SLOWER, 2.35 ms:
+// it needs 10-15 % more waves (a run ends at every occlusion gap) and a wave's time is set by how many different disparities its lanes
+// carry, not by whether its strips were staged.
+__global__ __launch_bounds__(256) void k_view_sort(Pm pm, int v, ViewCand vc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned int *s_cnt = reinterpret_cast<unsigned int *>(smem);  // W + 1 keys (key W: no target)
+  const int W = pm.W, y = blockIdx.x, nk = W + 1;
+  unsigned int *s_part = s_cnt + nk;                              // 256 partial sums
+  const Field &src = pm.f[1 - v];
+  const long long row = (long long)y * W;
+  for (int t = threadIdx.x; t < nk; t += blockDim.x) s_cnt[t] = 0u;
+  __syncthreads();
+  auto key_of = [&](int x) {
+    const long long i = row + x;
+    double disp = src.a[i] * (double)x + src.b[i] * (double)y + src.c[i];  // as view_proposal
+    if (disp < 0.0) disp = 0.0;
+    if (disp >= (double)pm.max_dis) disp = (double)pm.max_dis - 1.0;
+    const int r = round2int(disp);
+    const int cx = handle_border(v == 0 ? x + r : x - r, W);
+    return cx >= 0 && cx < W ? cx : W;
+  };
+  for (int x = threadIdx.x; x < W; x += blockDim.x) atomicAdd(&s_cnt[key_of(x)], 1u);
+  __syncthreads();
+  // exclusive scan of the W + 1 counts: every thread scans a contiguous run, thread 0 scans the 256 run totals
+  const int per = (nk + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int k0 = min((int)threadIdx.x * per, nk), k1 = min(k0 + per, nk);
+  unsigned int run = 0u;
+  for (int k = k0; k < k1; ++k) { const unsigned int n = s_cnt[k]; s_cnt[k] = run; run += n; }
+  s_part[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int acc = 0u;
+    for (int t = 0; t < (int)blockDim.x; ++t) { const unsigned int n = s_part[t]; s_part[t] = acc; acc += n; }
+  }
+  __syncthreads();
+  for (int k = k0; k < k1; ++k) s_cnt[k] += s_part[threadIdx.x];
+  __syncthreads();
+  for (int x = threadIdx.x; x < W; x += blockDim.x) vc.perm[row + atomicAdd(&s_cnt[key_of(x)], 1u)] = x;
+}
+
 template <bool CS, int SRC>
 __global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd, Pm pm, RowQueue rq, int v, ViewCand vc, int cap, int ocap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1516,13 +1565,14 @@ __global__ __launch_bounds__(kRowBlock, CSPM_VIEW_MINW) void k_view_eval(Cost cd
   RowItem it;
   if (!row_item(pm.W, pm.H, 1, rq, it)) return;
   const int lane = threadIdx.x & 63;
+  const int y = it.y;
+  const bool live = it.x0 + lane < pm.W;
+  const int slot = live ? it.x0 + lane : pm.W - 1;
+  const int x = vc.perm ? vc.perm[(long long)y * pm.W + slot] : slot;  // the slot's source column (tail lanes shadow the row's last proposal)
   RowCtx ctx = make_row_ctx(smem, it.y, cap, ocap);
 #ifdef CSPM_ROW_STATS
   ctx.stat_slot = 1;
 #endif
-  const bool live = it.x0 + lane < pm.W;
-  const int x = live ? it.x0 + lane : pm.W - 1;
-  const int y = it.y;
   const long long i = (long long)y * pm.W + x;
   const ViewProposal q0 = view_proposal(pm, v, x, y);
   const bool inside = q0.cor_x >= 0 && q0.cor_x < pm.W;

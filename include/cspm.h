@@ -144,6 +144,11 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * CSPM_OPT_FAULT_VOLUME_ALLOC (write only, TEST HOOK): the n-th optional-volume allocation of this context from now on fails as if
  * hipMalloc had returned out-of-memory; a set_option call, never the environment, so that no deployment can switch it on by accident. */
 #define CSPM_OPT_VOLUME_RETRY_PAIRS 15
+/* CSPM_OPT_VIEW_SORT (default 1): ViewPropagation (cs_patchmatch.cc:229-277) evaluates the proposals of a row in the order of their TARGET
+ * column instead of their source column, so that the 64 proposals of a wavefront land next to each other in the target view even where
+ * the source disparities jump (a depth edge); 0 = source order.  The accept rule (smallest cost, earliest in the reference's traversal
+ * among equals, :256-272) is applied afterwards per target pixel and does not depend on the order of evaluation: identical planes. */
+#define CSPM_OPT_VIEW_SORT 17
 #define CSPM_OPT_FAULT_VOLUME_ALLOC 16
 #define CSPM_OPT_SWEEP_PACKED 10
 #define CSPM_OPT_SWEEP_PACKED_ACTIVE 11

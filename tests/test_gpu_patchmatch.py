@@ -109,9 +109,14 @@ def test_row_shared_rng_quirk(gpu_ctx, small_pair):
     assert np.all(npar[:, :, :3] == npar[0:1, :, :3])  # identical normals down every column
 
 
-def test_set_planes_roundtrip_and_view_ties(gpu_ctx, small_pair):
+@pytest.mark.parametrize("view_sort", [1, 0])
+def test_set_planes_roundtrip_and_view_ties(gpu_ctx, small_pair, view_sort):
     """Collisions in view propagation: all source pixels of a row carry the same fronto-parallel plane,
-    so several of them hit one target with EQUAL cost; the first in traversal order must win."""
+    so several of them hit one target with EQUAL cost; the first in traversal order must win -- whether the proposals are evaluated
+    in target-column order (CSPM_OPT_VIEW_SORT, the default: equal targets then sit in neighbouring lanes in no particular order)
+    or in source order."""
+    from crossscalepatchmatch_amd import capi
+    gpu_ctx.set_option(capi.OPT_VIEW_SORT, view_sort)
     pc, pm = _setup(gpu_ctx, small_pair, 0, 0.0)
     h, w, D = small_pair["h"], small_pair["w"], small_pair["max_dis"]
     rng = np.random.default_rng(1)

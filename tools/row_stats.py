@@ -8,7 +8,12 @@ sys.path.insert(0, ROOT)
 os.environ["CSPM_LIB"] = os.path.join(ROOT, "crossscalepatchmatch_amd", "libcspm_rowstats.so")
 import crossscalepatchmatch_amd as cs
 from crossscalepatchmatch_amd import synth
-cfg, l, r, _, _ = synth.make_config(sys.argv[1] if len(sys.argv) > 1 else "C3")
+if len(sys.argv) > 1 and sys.argv[1] == "real":  # the Middlebury motorcycle pair (scikit-image's copy, or the committed crop)
+    from crossscalepatchmatch_amd import realdata
+    cfg, l, r, _ = realdata.load_full() or realdata.load_crop()
+else:
+    cfg, l, r, _, _ = synth.make_config(sys.argv[1] if len(sys.argv) > 1 else "C3")
+print("view propagation in", "TARGET order (CSPM_OPT_VIEW_SORT = 1)" if os.environ.get("CSPM_VIEW_SORT", "1") != "0" else "source order (CSPM_VIEW_SORT=0)")
 ctx = cs.StereoContext(0)
 L = cs.load_library()
 L.cspm_debug_rowstats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
