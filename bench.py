@@ -181,8 +181,8 @@ def main():
     ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C4 | C5 (crossscalepatchmatch_amd/synth.py); C4 = the batch of C3-shaped pairs "
                                                    "held by rank 0 and dispatched through crossscalepatchmatch_amd.batch.run_batch")
     ap.add_argument("--same-pair", action="store_true", help="time one pair K times instead of K distinct pairs (seeds base + k)")
-    ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams); with three or more the sweep runs "
-                                                            "one workgroup per CU (CSPM_OPT_SWEEP_WG: it then leaves the other pairs' kernels their registers)")
+    ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams); with two or more the sweep runs "
+                                                            "four-wave workgroups (CSPM_OPT_SWEEP_FOLD: they leave the other pairs' kernels their registers)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)
     ap.add_argument("--no-early-exit", action="store_true")
@@ -284,9 +284,9 @@ def main():
                 pair_fn.finalize()
     else:
         ctxs = [cs.StereoContext(dev_index) for _ in range(nfl)]  # each context owns a HIP stream
-        if nfl >= 3 and not os.environ.get("CSPM_SWEEP_WG"):
-            for ctx in ctxs:
-                ctx.set_option(capi.OPT_SWEEP_WG, 1)
+        if nfl >= 2 and not os.environ.get("CSPM_SWEEP_FOLD"):
+            for ctx in ctxs:  # the pairs share the GPU: four-wave sweep workgroups leave room for two of another pair's refinement workgroups (include/cspm.h)
+                ctx.set_option(capi.OPT_SWEEP_FOLD, 1)
     d_out = [[torch.empty((h, w), dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(nfl)]
     for ctx in ctxs:
         ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(args.raster_launches))
@@ -369,15 +369,15 @@ def main():
     # (same inputs, same code path; outside the timed region, which `value` comes from).
     solo = timing
     if nfl > 1:
-        wg_keep = ctxs[0].get_option(capi.OPT_SWEEP_WG)
-        ctxs[0].set_option(capi.OPT_SWEEP_WG, 0)  # a pair that is alone on the GPU runs the sweep with the library's default (2 workgroups per CU)
+        fold_keep = ctxs[0].get_option(capi.OPT_SWEEP_FOLD)
+        ctxs[0].set_option(capi.OPT_SWEEP_FOLD, 0)  # a pair that is alone on the GPU runs the sweep with the library's default (one wave per level)
         ctxs[0].enable_timing(not args.no_kernel_timing)
         ctxs[0].reset_timing()
         step(0, pair=args.steps - 1)
         ctxs[0].synchronize()
         solo = ctxs[0].timing()
         ctxs[0].enable_timing(False)
-        ctxs[0].set_option(capi.OPT_SWEEP_WG, wg_keep)
+        ctxs[0].set_option(capi.OPT_SWEEP_FOLD, fold_keep)
 
     bad_run = False
     if rank == 0:
@@ -395,6 +395,7 @@ def main():
                        "sweep_cells": "paired-cell volumes" if ctxs[0].get_option(capi.OPT_SWEEP_PAIRS_ACTIVE) else "as cost_source",
                        "raster_sweep": "per-diagonal launches" if args.raster_launches else "persistent", "rb_rounds": args.rb_rounds,
                        "sweep_workgroups_per_cu": ctxs[0].get_option(capi.OPT_SWEEP_WG) or 2,
+                       "sweep_workgroup_waves": ("levels - 1 (coarsest level folded, CSPM_OPT_SWEEP_FOLD)" if ctxs[0].get_option(capi.OPT_SWEEP_FOLD) else "one per level"),
                        "early_exit": not args.no_early_exit, "pairs_per_gpu": args.steps, "distinct_pairs_per_gpu": npairs, "pairs_in_flight_per_gpu": nfl, "use_pp": use_pp,
                        "parallelism": f"{world} rank(s), one per GPU, {nfl} independent pair stream(s) each",
                        "dispatch": ("batch.run_batch: rank 0 holds the %d pairs; broadcast of the parameters, chunked scatter of the pair blocks, "

@@ -57,13 +57,12 @@ class HipPairFn:
         from .capi import StereoContext
         self.device = torch.device("cuda", device_index)
         self.ctxs = [StereoContext(device_index) for _ in range(max(1, int(in_flight)))]  # raises CspmError without libcspm_hip.so / a device
-        if len(self.ctxs) >= 3:
-            # three or more pairs share the GPU: one sweep workgroup per CU leaves the others' refinements their registers (include/cspm.h).
-            # Only where nobody has chosen: a context that already carries a setting (the environment variable CSPM_SWEEP_WG) keeps it.
-            from .capi import OPT_SWEEP_WG
+        if len(self.ctxs) >= 2 and not os.environ.get("CSPM_SWEEP_FOLD"):
+            # the pairs share the GPU: four-wave sweep workgroups (the coarsest level folded) leave room for two of another pair's
+            # refinement workgroups per CU instead of one (include/cspm.h CSPM_OPT_SWEEP_FOLD); the environment variable, if set, decides
+            from .capi import OPT_SWEEP_FOLD
             for c in self.ctxs:
-                if c.get_option(OPT_SWEEP_WG) == 0:
-                    c.set_option(OPT_SWEEP_WG, 1)
+                c.set_option(OPT_SWEEP_FOLD, 1)
         # every context runs on the non-blocking HIP stream it owns; torch sees it as an ExternalStream for the waits below.  (Streams
         # from torch's pool may share a hardware queue -- with GPU_MAX_HW_QUEUES at its default, two of them did: the pairs of
         # two contexts then ran strictly one after the other, 192 instead of 172 ms per KITTI-size pair.)

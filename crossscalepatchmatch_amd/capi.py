@@ -30,6 +30,7 @@ OPT_SWEEP_WG = 14            # persistent sweep workgroups per CU (0 = default 2
 OPT_VOLUME_FALLBACKS = 9     # read only: hipMalloc failures of an optional volume this context survived
 OPT_VOLUME_RETRY_PAIRS = 15  # a cost object that runs without the optional volumes it wanted asks again after this many reuses (default 16, 0 = never)
 OPT_VIEW_SORT = 17           # view propagation evaluates a row's proposals in target-column order (default 1; identical planes either way)
+OPT_SWEEP_FOLD = 18          # cross-scale sweep workgroups of levels - 1 waves, the coarsest level folded onto them (default 1; identical planes)
 OPT_FAULT_VOLUME_ALLOC = 16  # write only, TEST HOOK: the n-th optional-volume allocation from now on fails
 
 # every symbol include/cspm.h declares

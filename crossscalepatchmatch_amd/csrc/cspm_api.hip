@@ -108,6 +108,7 @@ struct cspm_ctx {
   double *field_mem = nullptr;
   Field f[2]{};
   ViewCand vc{nullptr, nullptr, nullptr, nullptr};
+  long long opt_sweep_fold = 0;  // CSPM_OPT_SWEEP_FOLD: cross-scale sweep workgroups of levels - 1 waves, the last level folded onto them (for contexts that share their GPU)
   long long opt_view_sort = 1;  // CSPM_OPT_VIEW_SORT: view propagation evaluates a row's proposals in the order of their target column
   uint8_t *d_dis[2] = {nullptr, nullptr};
   uint8_t *d_valid[2] = {nullptr, nullptr};  // post-processing: left-right consistency flags
@@ -845,9 +846,12 @@ int do_init(cspm_ctx *c, const cspm_pm_params *p) {
 }
 
 // waves of a sweep workgroup: cross-scale -> one per pyramid level; single-scale -> one per chain pass of a full window
+inline bool sweep_folded(const cspm_ctx *c) { return c->cost.cs && kSweepWpl == 1 && c->opt_sweep_fold != 0 && c->cost.levels >= 4; }
 inline unsigned sweep_waves(const cspm_ctx *c) {
+  if (sweep_folded(c)) return (unsigned)(c->cost.levels - 1);  // the last level is folded onto the waves of levels 1 .. (cspm_chain.h eval_pixel_pair)
   return c->cost.cs ? (unsigned)(c->cost.levels * kSweepWpl) : (unsigned)((c->cost.n + kChainRows - 1) / kChainRows);
 }
+inline size_t sweep_lds(const cspm_ctx *c) { return sweep_shared_bytes((int)sweep_waves(c) + (sweep_folded(c) ? 1 : 0)); }
 
 int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
   Pm pm = make_pm(c, p);
@@ -909,8 +913,8 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
     const unsigned waves = sweep_waves(c);
     {
       Timed t(c, CSPM_K_SPATIAL, (long long)sw.total * 2);
-      if (flow) LAUNCH_SWEEP(k_spatial_flow, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
-      else LAUNCH_SWEEP(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_shared_bytes((int)waves), c->cost, pm, sw, inc);
+      if (flow) LAUNCH_SWEEP(k_spatial_flow, dim3(grid), dim3(waves * kWave), sweep_lds(c), c->cost, pm, sw, inc);
+      else LAUNCH_SWEEP(k_spatial_sweep, dim3(grid), dim3(waves * kWave), sweep_lds(c), c->cost, pm, sw, inc);
     }
     c->sweep_pending = true;
   } else {
@@ -918,7 +922,7 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       const int ys_lo = std::max(0, k - (c->W - 1)), ys_hi = std::min(c->H - 1, k);
       const long long items = 2LL * (ys_hi - ys_lo + 1);
       Timed t(c, CSPM_K_SPATIAL, items * 2);
-      LAUNCH_SWEEP(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), sweep_shared_bytes((int)sweep_waves(c)), c->cost, pm, k, inc);
+      LAUNCH_SWEEP(k_spatial_diag, dim3((unsigned)items), dim3(sweep_waves(c) * kWave), sweep_lds(c), c->cost, pm, k, inc);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -1067,6 +1071,7 @@ int cspm_create(cspm_ctx **out, int device) {
   if (const char *e = getenv("CSPM_SWEEP_PACKED")) c->opt_sweep_packed = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_SWEEP_FLOW")) c->opt_sweep_flow = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VIEW_SORT")) c->opt_view_sort = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("CSPM_SWEEP_FOLD")) c->opt_sweep_fold = atoi(e) ? 1 : 0;
   if (const char *e = getenv("CSPM_VOLUMES_MEM_FRACTION")) c->volumes_mem_fraction = std::min(1.0, std::max(0.0, atof(e)));
   if (const char *e = getenv("CSPM_SWEEP_PAIRS_MAX_MB")) c->sweep_pairs_limit = std::max(0LL, atoll(e)) << 20;
   if (const char *e = getenv("CSPM_SWEEP_TIMEOUT_MS")) c->sweep_timeout_ms = std::min(3600000LL, std::max(0LL, atoll(e)));
@@ -1185,6 +1190,7 @@ int cspm_set_option(cspm_ctx *c, int key, long long value) {
     case CSPM_OPT_SWEEP_FLOW: c->opt_sweep_flow = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: c->sweep_wg_per_cu = value < 0 ? 0 : (value > 16 ? 16 : (int)value); return CSPM_OK;
     case CSPM_OPT_VIEW_SORT: c->opt_view_sort = value ? 1 : 0; return CSPM_OK;
+    case CSPM_OPT_SWEEP_FOLD: c->opt_sweep_fold = value ? 1 : 0; return CSPM_OK;
     case CSPM_OPT_FAULT_VOLUME_ALLOC: c->fault_volume_alloc = value < 0 ? 0 : (int)value; return CSPM_OK;
     case CSPM_OPT_VOLUME_RETRY_PAIRS: c->volume_retry_pairs = value < 0 ? 0 : value; return CSPM_OK;
     case CSPM_OPT_SWEEP_TIMEOUT_MS:
@@ -1209,6 +1215,7 @@ int cspm_get_option(cspm_ctx *c, int key, long long *value) {
     case CSPM_OPT_VOLUME_FALLBACKS: *value = c->optional_volume_fallbacks; return CSPM_OK;
     case CSPM_OPT_VOLUME_RETRY_PAIRS: *value = c->volume_retry_pairs; return CSPM_OK;
     case CSPM_OPT_VIEW_SORT: *value = c->opt_view_sort; return CSPM_OK;
+    case CSPM_OPT_SWEEP_FOLD: *value = c->opt_sweep_fold; return CSPM_OK;
     case CSPM_OPT_SWEEP_PACKED: *value = c->opt_sweep_packed; return CSPM_OK;
     case CSPM_OPT_SWEEP_FLOW: *value = c->opt_sweep_flow; return CSPM_OK;
     case CSPM_OPT_SWEEP_WG: *value = c->sweep_wg_per_cu; return CSPM_OK;

@@ -606,6 +606,46 @@ __device__ __forceinline__ void eval_pixel_pair(const Cost &cd, const Luts &lut,
         }
       }
     }
+    // FOLDED last level (round 6, CSPM_OPT_SWEEP_FOLD): a workgroup launched with ONE WAVE FEWER than the cost has levels -- four waves,
+    // one per SIMD, for the usual five levels -- evaluates the last (coarsest) level with the waves of levels 1 .. nw-1 once they have
+    // finished their own: they share its chain passes (a 78 x 24 level of a KITTI-size pair has three), the chain sums meet in the
+    // scratch behind the waves' own, and two of them finish the two candidates.  Same taps, same chains, same row tree: identical sums.
+    // Why: a five-wave workgroup sits 2 + 1 + 1 + 1 on the four SIMDs and two of them leave room for ONE four-wave workgroup of another
+    // pair's refinement (168 VGPRs) where three run on an empty CU; two four-wave sweep workgroups leave room for TWO
+    // (profiles/r06_corun.txt: the refinement runs at 36 % of its speed beside a sweep, the sweep is not slowed at all).
+    const int nw = (int)(blockDim.x >> 6);
+    if (kSweepWpl == 1 && cd.levels == nw + 1) {
+      const int last = cd.levels - 1;
+      double *fold0 = sh.m[nw].part[0], *fold1 = sh.m[nw].part[1];
+      ChainLevel B = A;
+      if (wave >= 1) {
+        double e0 = c0.a * (double)x + c0.b * (double)y + c0.c, e1 = c1.a * (double)x + c1.b * (double)y + c1.c;
+        int lx = x, ly = y;
+        for (int s = 0; s < last; ++s) { ly /= 2; lx /= 2; e0 /= 2.0; e1 /= 2.0; }
+        B = make_chain_level<SRC>(cd, last, v, lx, ly);
+        ChainPlane pl[2];
+        plane_param(c0.nx, c0.ny, c0.nz, (double)lx, (double)ly, e0, pl[0].a, pl[0].b, pl[0].c);
+        pl[0].a = wave_uniform(pl[0].a); pl[0].b = wave_uniform(pl[0].b); pl[0].c = wave_uniform(pl[0].c);
+        if (both) {
+          plane_param(c1.nx, c1.ny, c1.nz, (double)lx, (double)ly, e1, pl[1].a, pl[1].b, pl[1].c);
+          pl[1].a = wave_uniform(pl[1].a); pl[1].b = wave_uniform(pl[1].b); pl[1].c = wave_uniform(pl[1].c);
+          double *const parts[2] = {fold0, fold1};
+          chain_passes<SRC, 2, CSPM_SWEEP_PIPE != 0>(cd, B, lut, pl, lane, wave - 1, nw - 1, parts);
+        } else {
+          const ChainPlane p1[1] = {pl[0]};
+          double *const parts[1] = {fold0};
+          chain_passes<SRC, 1, CSPM_SWEEP_PIPE != 0>(cd, B, lut, p1, lane, wave - 1, nw - 1, parts);
+        }
+      }
+      __syncthreads();  // the folded level's chain sums are complete
+      if (wave == 1) {
+        const double s0 = finish_level(B, fold0, lane);
+        if (lane == 0) { sh.lvl[0][last] = s0; if (!both) sh.lvl[1][last] = s0; }
+      } else if (wave == 2 && both) {
+        const double s1 = finish_level(B, fold1, lane);
+        if (lane == 0) sh.lvl[1][last] = s1;
+      }
+    }
     __syncthreads();
     cost0 = cost1 = 0.0;
     if (wave == 0) {

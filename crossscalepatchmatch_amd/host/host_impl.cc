@@ -138,7 +138,8 @@ void DevicePlaneCost::open_context(const Mat &l_img, const Mat &r_img) {
   if (!ctx_) {
     check(cspm_create(&ctx_, slot_->device()), NULL, "cspm_create");
     adopt(ctx_);
-    if (slot_->sweep_wg() > 0) check(cspm_set_option(ctx_, CSPM_OPT_SWEEP_WG, slot_->sweep_wg()), ctx_, "cspm_set_option");
+    if (slot_->shared_gpu() && !std::getenv("CSPM_SWEEP_FOLD"))  // the environment variable, if set, has decided at cspm_create
+      check(cspm_set_option(ctx_, CSPM_OPT_SWEEP_FOLD, 1), ctx_, "cspm_set_option");
   }
   base_sweep_fallbacks_ = option(ctx_, CSPM_OPT_SWEEP_FALLBACKS);
   base_volume_fallbacks_ = option(ctx_, CSPM_OPT_VOLUME_FALLBACKS);

@@ -44,7 +44,7 @@ DEFINE_string(batch_list, "", "text file, one stereo pair per line: l_img r_img 
                               "that fails is reported and the batch goes on; the exit code is non-zero if any pair failed");
 DEFINE_int32(in_flight, 3, "with --batch_list: stereo pairs in flight per GPU.  Each is a worker thread with its own device context (one HIP stream): "
                            "it decodes its pair's PNGs, runs it and encodes the maps while the other workers' kernels keep the GPU busy (the raster "
-                           "sweep of one pair leaves most CUs idle).  With 3 or more the sweep runs one workgroup per CU (CSPM_OPT_SWEEP_WG)");
+                           "sweep of one pair leaves most CUs idle).  With 2 or more the sweep runs four-wavefront workgroups (CSPM_OPT_SWEEP_FOLD)");
 DEFINE_string(devices, "", "with --batch_list: GPUs to spread the pairs over: a comma-separated list of indices (an index may repeat: that many "
                            "worker sets on that GPU) or `all`; empty = --device.  Pairs are independent: no data moves between GPUs");
 DEFINE_bool(batch_skip_existing, false, "with --batch_list: skip the pairs whose output maps already exist (restart an interrupted batch)");
@@ -188,7 +188,7 @@ int run_batch(const std::vector<BatchJob> &jobs, int skipped, int bad_lines) {
   std::mutex out_mutex;
   const double t0 = static_cast<double>(getTickCount());
   auto worker = [&](int device) {
-    DeviceSlot slot(device, /*keep_context=*/true, /*sweep_wg=*/on_gpu[device] >= 3 ? 1 : 0);
+    DeviceSlot slot(device, /*keep_context=*/true, /*shared_gpu=*/on_gpu[device] >= 2);
     DeviceSlot::Use use(slot);
     const std::unique_ptr<CCMethod> cost_fn(GetCCType(FLAGS_cc_name));  // NULL for unknown names, rejected by the cost constructors
     // the next pair of the queue, decoded; a pair whose files cannot be read is reported at once and the worker moves on

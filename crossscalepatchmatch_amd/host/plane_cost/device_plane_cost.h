@@ -15,14 +15,14 @@
 class DeviceSlot {
  public:
   // keep_context: a destroyed cost object parks its cspm_ctx (device buffers included) here for the next object of the slot, so a stream
-  // of equally sized pairs allocates once.  sweep_wg: CSPM_OPT_SWEEP_WG of the contexts opened through the slot (0 = the library's
-  // default; 1 when three or more pairs are in flight on the GPU, include/cspm.h).
-  explicit DeviceSlot(int device = 0, bool keep_context = false, int sweep_wg = 0)
-      : device_(device), keep_(keep_context), sweep_wg_(sweep_wg), parked_(NULL), sweep_fallbacks_(0), volume_fallbacks_(0) {}
+  // of equally sized pairs allocates once.  shared_gpu: other slots keep pairs in flight on the same GPU -- the contexts opened through
+  // this one then get CSPM_OPT_SWEEP_FOLD (four-wavefront sweep workgroups that leave the other pairs' kernels room, include/cspm.h).
+  explicit DeviceSlot(int device = 0, bool keep_context = false, bool shared_gpu = false)
+      : device_(device), keep_(keep_context), shared_gpu_(shared_gpu), parked_(NULL), sweep_fallbacks_(0), volume_fallbacks_(0) {}
   ~DeviceSlot() { release(); }
   int device() const { return device_; }
   bool keep_context() const { return keep_; }
-  int sweep_wg() const { return sweep_wg_; }
+  bool shared_gpu() const { return shared_gpu_; }
   void release();  // destroy the parked context, if any
   // sums over the contexts this slot has seen: raster sweeps repeated after a hand-over timeout / optional volumes given up (include/cspm.h)
   long long sweep_fallbacks() const { return sweep_fallbacks_; }
@@ -47,7 +47,7 @@ class DeviceSlot {
   bool park(cspm_ctx *ctx);    // false: not a keeping slot / already holds one -- the caller destroys ctx
   int device_;
   bool keep_;
-  int sweep_wg_;
+  bool shared_gpu_;
   cspm_ctx *parked_;
   long long sweep_fallbacks_, volume_fallbacks_;
 };

@@ -149,6 +149,15 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * the source disparities jump (a depth edge); 0 = source order.  The accept rule (smallest cost, earliest in the reference's traversal
  * among equals, :256-272) is applied afterwards per target pixel and does not depend on the order of evaluation: identical planes. */
 #define CSPM_OPT_VIEW_SORT 17
+/* CSPM_OPT_SWEEP_FOLD (default 0; cross-scale costs with 4 or more levels): 1 = the raster sweep's workgroups have one wavefront FEWER than
+ * the cost has pyramid levels -- four, one per SIMD, for the reference's five levels (main.cc:100) -- and the coarsest level is evaluated by
+ * the wavefronts of levels 1.. after their own; 0 = one wavefront per level.  Same taps and sums: identical planes.  For callers that keep
+ * TWO OR MORE pairs in flight on one GPU (contexts on separate streams): a CU that holds two four-wavefront sweep workgroups has room for
+ * two workgroups of another pair's refinement where two five-wavefront ones leave room for one (of three), so the refinement beside a
+ * sweep runs at 2/3 instead of 1/3 of its speed -- measured with 3 pairs in flight: 137.9 against 142.8 ms per KITTI-size pair.  A pair
+ * that has the GPU to itself is slower folded (a sweep takes 23.0 instead of 20.2 ms: three wavefronts walk 5 window passes instead of 4).
+ * With it, CSPM_OPT_SWEEP_WG stays at its default (2) also for three pairs in flight. */
+#define CSPM_OPT_SWEEP_FOLD 18
 #define CSPM_OPT_FAULT_VOLUME_ALLOC 16
 #define CSPM_OPT_SWEEP_PACKED 10
 #define CSPM_OPT_SWEEP_PACKED_ACTIVE 11

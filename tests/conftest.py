@@ -47,7 +47,7 @@ def gpu_ctx(_gpu_ctx_session):
     ctx = _gpu_ctx_session
     for key, value in ((capi.OPT_GRD_VOLUMES, 0), (capi.OPT_SWEEP_PAIRS, 0), (capi.OPT_TABLE_VOLUMES, 1), (capi.OPT_RASTER_LAUNCHES, 0),
                        (capi.OPT_SWEEP_TIMEOUT_MS, 3000), (capi.OPT_SWEEP_PACKED, 0), (capi.OPT_SWEEP_FLOW, 0), (capi.OPT_SWEEP_WG, 0),
-                       (capi.OPT_VOLUME_RETRY_PAIRS, 16), (capi.OPT_VIEW_SORT, 1)):
+                       (capi.OPT_VOLUME_RETRY_PAIRS, 16), (capi.OPT_VIEW_SORT, 1), (capi.OPT_SWEEP_FOLD, 0)):
         ctx.set_option(key, value)
     return ctx
 

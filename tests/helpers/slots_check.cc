@@ -18,7 +18,7 @@ static std::atomic<int> g_failed(0);
 
 static void one_thread(const Mat &l, const Mat &r, int max_dis, int t, int pairs, int device, const std::string &prefix) {
   try {
-    DeviceSlot slot(device, /*keep_context=*/true);
+    DeviceSlot slot(device, /*keep_context=*/true, /*shared_gpu=*/t >= 2);  // threads 2.. run the folded sweep (CSPM_OPT_SWEEP_FOLD): same maps
     GrdCC cc(device);
     for (int k = 0; k < pairs; ++k) {
       std::unique_ptr<IPlaneCost> pc;

@@ -328,6 +328,27 @@ def test_c3_persistent_sweep_vs_per_diagonal_launches(gpu_ctx, c3):
         gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
 
 
+def test_c3_folded_sweep_equals_one_wave_per_level(gpu_ctx, c3):
+    """CSPM_OPT_SWEEP_FOLD at the headline size (what bench.py, batch.HipPairFn and cspm_main's batch workers run with several pairs in
+    flight): four-wave sweep workgroups, the 78 x 24 level's three window passes shared by the waves of levels 1-3 -- three whole
+    iterations identical to the one-wave-per-level sweep, plane for plane."""
+    from crossscalepatchmatch_amd import capi
+    cfg, l, r, _, _ = c3
+    gpu_ctx.set_images(l, r)
+    gpu_ctx.build_cost_grd(cfg["max_dis"], 35, cfg["scale_num"], cfg["reg_lambda"])
+    out = []
+    try:
+        for fold in (0, 1):
+            gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, fold)
+            gpu_ctx.patchmatch(3, seed=77, schedule=0)
+            out.append([gpu_ctx.get_planes(v) for v in (0, 1)])
+    finally:
+        gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, 0)
+    for v in (0, 1):
+        np.testing.assert_array_equal(out[0][v][0], out[1][v][0])
+        np.testing.assert_array_equal(out[0][v][1], out[1][v][1])
+
+
 def test_c3_view_propagation_target_order_equals_source_order(gpu_ctx, c3):
     """ViewPropagation's proposals evaluated in the order of their target column (round 6, CSPM_OPT_VIEW_SORT = 1, the default) or of
     their source column: the accept rule is applied per target pixel afterwards (k_view_resolve), so three whole iterations at the

@@ -567,3 +567,38 @@ def test_wide_disparity_range(gpu_ctx):
     pm.run(1, pc, False, seed=8, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
     gpu_ctx.patchmatch(1, seed=8, schedule=0)
     _assert_state_equal(gpu_ctx, pm, "max_dis 300")
+
+
+@pytest.mark.parametrize("scale_num", [5, 4])
+def test_folded_sweep_workgroups_equal_the_oracle(gpu_ctx, odd_pair, mid_pair, scale_num):
+    """CSPM_OPT_SWEEP_FOLD (round 6, what callers with several pairs in flight switch on): sweep workgroups of levels - 1 waves, the
+    coarsest level's window passes shared by the waves of levels 1.. -- the persistent sweep, the per-diagonal launches and the whole
+    pipeline give the oracle's planes bit for bit, with five levels (four waves) and with four (three waves)."""
+    from crossscalepatchmatch_amd import capi
+    for pair in (odd_pair, mid_pair):
+        pc, pm = _setup(gpu_ctx, pair, scale_num, 0.3)
+        try:
+            gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, 1)
+            pm.init(pc, seed=3, sum_order=po.SUM_DEVICE); gpu_ctx.pm_init(seed=3)
+            for it in (0, 1):
+                for launches in (0, 1):
+                    gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, launches)
+                    start = [gpu_ctx.get_planes(v) for v in (0, 1)]
+                    gpu_ctx.pm_spatial(it, seed=3)
+                    if launches == 0:
+                        first = [gpu_ctx.get_planes(v) for v in (0, 1)]
+                        for v in (0, 1):
+                            gpu_ctx.set_planes(v, *start[v])
+                    else:
+                        for v in (0, 1):
+                            np.testing.assert_array_equal(gpu_ctx.get_planes(v)[0], first[v][0])
+                            np.testing.assert_array_equal(gpu_ctx.get_planes(v)[1], first[v][1])
+                pm.spatial(it, pc, seed=3, sum_order=po.SUM_DEVICE)
+                _assert_state_equal(gpu_ctx, pm, f"folded sweep, {scale_num} levels, iteration {it}")
+            gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
+            pm.run(2, pc, False, seed=8, schedule=po.SCHED_RASTER, sum_order=po.SUM_DEVICE)
+            gpu_ctx.patchmatch(2, seed=8, schedule=po.SCHED_RASTER)
+            _assert_state_equal(gpu_ctx, pm, f"folded sweep, {scale_num} levels, whole run")
+        finally:
+            gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, 0)
+            gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
