@@ -159,8 +159,10 @@ void DevicePlaneCost::open_context(const Mat &l_img, const Mat &r_img) {
 void DevicePlaneCost::close_context() {
   if (!ctx_) return;
   if (slot_) {
-    slot_->sweep_fallbacks_ += option(ctx_, CSPM_OPT_SWEEP_FALLBACKS) - base_sweep_fallbacks_;
-    slot_->volume_fallbacks_ += option(ctx_, CSPM_OPT_VOLUME_FALLBACKS) - base_volume_fallbacks_;
+    const long long ds = option(ctx_, CSPM_OPT_SWEEP_FALLBACKS) - base_sweep_fallbacks_, dv = option(ctx_, CSPM_OPT_VOLUME_FALLBACKS) - base_volume_fallbacks_;
+    std::lock_guard<std::mutex> lock(g_host_mutex);  // the default slot is shared by every thread that names none
+    slot_->sweep_fallbacks_ += ds;
+    slot_->volume_fallbacks_ += dv;
   }
   if (!(slot_ && slot_->park(ctx_))) {
     disown(ctx_);

@@ -148,11 +148,11 @@ struct BatchJob {
 // --devices: "" -> {--device}; "all" -> every GPU; "0,1,1" -> those indices (repeats allowed).  Empty result = bad flag.
 std::vector<int> parse_devices() {
   std::vector<int> out;
+  const int n = DeviceSlot::device_count();
   if (FLAGS_devices.empty()) {
-    out.push_back(FLAGS_device);
+    if (FLAGS_device >= 0 && FLAGS_device < n) out.push_back(FLAGS_device);
     return out;
   }
-  const int n = DeviceSlot::device_count();
   if (FLAGS_devices == "all") {
     for (int d = 0; d < n; ++d) out.push_back(d);
     return out;
@@ -176,7 +176,8 @@ std::vector<int> parse_devices() {
 int run_batch(const std::vector<BatchJob> &jobs, int skipped, int bad_lines) {
   const std::vector<int> devices = parse_devices();
   if (devices.empty()) {
-    cout << "Error: --devices must be `all` or a comma-separated list of GPU indices below " << DeviceSlot::device_count() << "\n";
+    cout << "Error: --devices must be `all` or a comma-separated list of GPU indices below " << DeviceSlot::device_count()
+         << " (--device likewise); this node has " << DeviceSlot::device_count() << " usable GPU(s)\n";
     return EXIT_FAILURE;
   }
   const int per_gpu = std::max(1, FLAGS_in_flight);

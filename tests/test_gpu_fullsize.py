@@ -141,7 +141,7 @@ def test_c2_whole_pipeline_bit_exact(gpu_ctx):
     # ... and the north-star bar on the same run (one GPU run, one oracle cost object for both legs): the oracle in the REFERENCE order
     # (serial raster sweep, serial window sum, no FMA), identical inputs and random numbers, >= 99.5 % of both views within 0.5 px
     pm2 = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
-    pm2.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL)
+    pm2.run(3, pc, False, seed=12345, schedule=po.SCHED_RASTER, sum_order=po.SUM_SERIAL, wavefront=True)  # C1's leg keeps the sweep serial
     for v in (0, 1):
         d = np.abs(gpu_ctx.disparity_f64(v) - pm2.disp_f64(v))
         assert float(np.mean(d <= 0.5)) >= 0.995, (v, float(np.mean(d <= 0.5)), float(d.max()))
