@@ -134,10 +134,11 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
  * successor goes to a queue idle workgroups pop); 0 = workgroups claim pixels in diagonal-major order and wait for their predecessors.
  * The dependencies, hence the planes, are the same: the reference's in-place raster order (cs_patchmatch.cc:163-216). */
 #define CSPM_OPT_SWEEP_FLOW 13
-/* CSPM_OPT_SWEEP_WG (default 0 = 2): workgroups of the persistent raster sweep launched per CU.  A pair that has the GPU to itself wants 2
- * (one: 87 instead of 59 ms of sweeps per KITTI-size pair; more are not resident).  A caller that keeps THREE OR MORE pairs in flight on one
- * GPU (contexts on separate streams) should set 1: the sweep's workgroups hold registers and LDS that the other pairs' throughput kernels
- * would use -- measured with 3 pairs in flight: 146.5 ms per pair with 1, 150.6 with 2, 152.1 with 3. */
+/* CSPM_OPT_SWEEP_WG (default 0 = the library chooses): workgroups of the persistent raster sweep launched per CU.  The library's choice is 2 --
+ * a KITTI-size sweep is bound by its dependency chain (one: 29 instead of 20 ms per sweep; three: no faster) and every resident workgroup
+ * holds registers another pair's kernels would use -- and 3 for images whose anti-diagonals are many times wider than the resident
+ * workgroups (2 * min(w, h) >= 8 * CUs, e.g. 3000 x 2000: 214 instead of 279 ms per sweep) unless CSPM_OPT_SWEEP_FOLD says that the GPU is
+ * shared.  Any value gives identical planes. */
 #define CSPM_OPT_SWEEP_WG 14
 /* CSPM_OPT_VOLUME_RETRY_PAIRS (default 16; 0 = never): a cost object that wanted optional volumes and runs without them (free-memory veto
  * or a failed hipMalloc, see CSPM_OPT_TABLE_VOLUMES) asks for them again after this many pairs have reused it.
