@@ -10,9 +10,9 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank pr
 (weak scaling, no data-path collective), value = all pairs' pixels / max-over-ranks time.
 `python bench.py --gpus N` without a launcher spawns the N ranks itself.
 
-Pairs are independent units: by default three of them are in flight per GPU (three contexts, three HIP streams), so the
-CUs the raster sweep of one pair leaves idle (short anti-diagonals) evaluate the other pair's planes; all K pairs
-complete inside the timed region.  --in-flight 1 gives the one-pair-at-a-time number.
+Pairs are independent units: by default two of them are in flight per GPU (two contexts, two HIP streams; with the folded sweep of round 6
+two measure 135.7 ms per pair, three 136.8, four 137.7), so the CUs the raster sweep of one pair leaves idle evaluate the other pair's
+planes; all K pairs complete inside the timed region.  --in-flight 1 gives the one-pair-at-a-time number.
 
 Prints ONE JSON line (rank 0).
 """
@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C4 | C5 (crossscalepatchmatch_amd/synth.py); C4 = the batch of C3-shaped pairs "
                                                    "held by rank 0 and dispatched through crossscalepatchmatch_amd.batch.run_batch")
     ap.add_argument("--same-pair", action="store_true", help="time one pair K times instead of K distinct pairs (seeds base + k)")
-    ap.add_argument("--in-flight", type=int, default=3, help="stereo pairs in flight per GPU (contexts / HIP streams); with two or more the sweep runs "
+    ap.add_argument("--in-flight", type=int, default=2, help="stereo pairs in flight per GPU (contexts / HIP streams); with two or more the sweep runs "
                                                             "four-wave workgroups (CSPM_OPT_SWEEP_FOLD: they leave the other pairs' kernels their registers)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)

@@ -42,7 +42,7 @@ DEFINE_string(r_disp_pfm, "", "also write the right sub-pixel disparity map as f
 DEFINE_string(batch_list, "", "text file, one stereo pair per line: l_img r_img l_dis r_dis [l_pfm r_pfm]; all pairs run with the "
                               "matching flags of this command line on one device context (buffers are reused between pairs). A pair "
                               "that fails is reported and the batch goes on; the exit code is non-zero if any pair failed");
-DEFINE_int32(in_flight, 3, "with --batch_list: stereo pairs in flight per GPU.  Each is a worker thread with its own device context (one HIP stream): "
+DEFINE_int32(in_flight, 2, "with --batch_list: stereo pairs in flight per GPU (2 measured best on MI355X, 3 and 4 within 1.5 %).  Each is a worker thread with its own device context (one HIP stream): "
                            "it decodes its pair's PNGs, runs it and encodes the maps while the other workers' kernels keep the GPU busy (the raster "
                            "sweep of one pair leaves most CUs idle).  With 2 or more the sweep runs four-wavefront workgroups (CSPM_OPT_SWEEP_FOLD)");
 DEFINE_string(devices, "", "with --batch_list: GPUs to spread the pairs over: a comma-separated list of indices (an index may repeat: that many "
