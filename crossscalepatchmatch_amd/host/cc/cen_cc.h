@@ -9,7 +9,8 @@
 
 class CenCC : public CCMethod {
  public:
-  explicit CenCC(int device = 0) : device_(device) {}
+  // device < 0 (default): the GPU of the calling thread's DeviceSlot at the time of the call (plane_cost/device_plane_cost.h)
+  explicit CenCC(int device = -1) : device_(device) {}
   ~CenCC() {}
   void buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol);
   void buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol);

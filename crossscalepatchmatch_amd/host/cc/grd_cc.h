@@ -12,7 +12,8 @@
 
 class GrdCC : public CCMethod {
  public:
-  explicit GrdCC(int device = 0) : device_(device) {}
+  // device < 0 (default): the GPU of the calling thread's DeviceSlot at the time of the call (plane_cost/device_plane_cost.h)
+  explicit GrdCC(int device = -1) : device_(device) {}
   ~GrdCC() {}
   void buildCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *costVol);
   void buildRightCV(const Mat &lImg, const Mat &rImg, const int maxDis, Mat *rCostVol);

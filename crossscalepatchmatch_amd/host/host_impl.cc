@@ -29,7 +29,7 @@ void GrdCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int ri
   CV_Assert(lImg.rows == rImg.rows && lImg.cols == rImg.cols && maxDis >= 1 && vol);
   const int h = lImg.rows, w = lImg.cols;
   std::vector<double> l = packed64(lImg), r = packed64(rImg), out((size_t)maxDis * h * w);
-  check(cspm_grd_build_cv_host(device_, l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "GrdCC");
+  check(cspm_grd_build_cv_host(device_ >= 0 ? device_ : DeviceSlot::current().device(), l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "GrdCC");
   for (int d = 0; d < maxDis; ++d) {
     if (vol[d].rows != h || vol[d].cols != w || vol[d].type() != CV_64FC1) vol[d].create(h, w, CV_64FC1);
     for (int y = 0; y < h; ++y) std::memcpy(vol[d].ptr<double>(y), &out[((size_t)d * h + y) * w], sizeof(double) * w);
@@ -44,7 +44,7 @@ void CenCC::build(const Mat &lImg, const Mat &rImg, int maxDis, Mat *vol, int ri
   CV_Assert(lImg.rows == rImg.rows && lImg.cols == rImg.cols && maxDis >= 1 && vol);
   const int h = lImg.rows, w = lImg.cols;
   std::vector<double> l = packed64(lImg), r = packed64(rImg), out((size_t)maxDis * h * w);
-  check(cspm_cen_build_cv_host(device_, l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "CenCC");
+  check(cspm_cen_build_cv_host(device_ >= 0 ? device_ : DeviceSlot::current().device(), l.data(), r.data(), w, h, maxDis, right, out.data()), NULL, "CenCC");
   for (int d = 0; d < maxDis; ++d) {
     if (vol[d].rows != h || vol[d].cols != w || vol[d].type() != CV_64FC1) vol[d].create(h, w, CV_64FC1);
     for (int y = 0; y < h; ++y) std::memcpy(vol[d].ptr<double>(y), &out[((size_t)d * h + y) * w], sizeof(double) * w);

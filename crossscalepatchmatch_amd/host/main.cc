@@ -169,7 +169,7 @@ std::vector<int> parse_devices() {
 }
 
 // The batch: pairs are independent units.  One worker thread per (entry of --devices, slot of --in_flight), each with
-// its own DeviceSlot -- GPU index, parked context whose buffers the next pair of the worker takes over, sweep workgroups per CU -- and
+// its own DeviceSlot -- GPU index, parked context whose buffers the next pair of the worker takes over, whether it shares its GPU -- and
 // its own CCMethod object; the workers pull pairs from one queue.  A worker blocks on its own pair only (cspm_ctx = one HIP stream), so
 // file decoding / encoding and the serial phases of one pair overlap with the kernels of the others.  Results do not depend on the
 // worker or GPU a pair lands on (same seed, same kernels): the maps equal the one-pair-at-a-time run bit for bit.
@@ -216,15 +216,21 @@ int run_batch(const std::vector<BatchJob> &jobs, int skipped, int bad_lines) {
     // software pipeline: while pair k is on the GPU the worker decodes pair k+1; as soon as k's maps are on the host, k+1 is
     // enqueued (on the context k just parked) and only then are k's maps encoded and written -- the worker's stream idles for the
     // download and the upload only, not for the files
-    std::unique_ptr<PairRun> cur = next_loaded();
-    if (cur) begin(*cur, cost_fn.get());
-    while (cur) {
-      std::unique_ptr<PairRun> nxt = next_loaded();
-      finish(*cur);
-      if (nxt) begin(*nxt, cost_fn.get());
-      write(*cur);
-      report(*cur);
-      cur = std::move(nxt);
+    try {
+      std::unique_ptr<PairRun> cur = next_loaded();
+      if (cur) begin(*cur, cost_fn.get());
+      while (cur) {
+        std::unique_ptr<PairRun> nxt = next_loaded();
+        finish(*cur);
+        if (nxt) begin(*nxt, cost_fn.get());
+        write(*cur);
+        report(*cur);
+        cur = std::move(nxt);
+      }
+    } catch (const std::exception &e) {  // the stages catch per pair; what still gets here (out of memory on the host ...) ends this worker, not the process
+      ++failed;
+      std::lock_guard<std::mutex> lock(out_mutex);
+      cout << "Error: batch worker on GPU " << device << " stopped: " << e.what() << "\n" << std::flush;
     }
     slot.release();
     sweep_fallbacks += slot.sweep_fallbacks();
