@@ -11,7 +11,7 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank pr
 `python bench.py --gpus N` without a launcher spawns the N ranks itself.
 
 Pairs are independent units: by default two of them are in flight per GPU (two contexts, two HIP streams; with the folded sweep of round 6
-two measure 135.7 ms per pair, three 136.8, four 137.7), so the CUs the raster sweep of one pair leaves idle evaluate the other pair's
+two measure 135.7 ms per pair, three 136.8, four 137.7; four for the small configurations C1 / C2), so the CUs the raster sweep of one pair leaves idle evaluate the other pair's
 planes; all K pairs complete inside the timed region.  --in-flight 1 gives the one-pair-at-a-time number.
 
 Prints ONE JSON line (rank 0).
@@ -181,7 +181,9 @@ def main():
     ap.add_argument("--config", default="C3", help="C1 | C2 | C3 | C4 | C5 (crossscalepatchmatch_amd/synth.py); C4 = the batch of C3-shaped pairs "
                                                    "held by rank 0 and dispatched through crossscalepatchmatch_amd.batch.run_batch")
     ap.add_argument("--same-pair", action="store_true", help="time one pair K times instead of K distinct pairs (seeds base + k)")
-    ap.add_argument("--in-flight", type=int, default=2, help="stereo pairs in flight per GPU (contexts / HIP streams); with two or more the sweep runs "
+    ap.add_argument("--in-flight", type=int, default=0, help="stereo pairs in flight per GPU (contexts / HIP streams); 0 (default) = by image size: 2 for KITTI-size pairs and larger "
+                                                            "(measured 135.7 ms per C3 pair against 136.8 with 3), 4 below 400 000 pixels (C1 / C2: 19.1 / 57.6 ms against "
+                                                            "20.7 / 60.1 with 2 -- small kernels leave more of the GPU idle).  With two or more the sweep runs "
                                                             "four-wave workgroups (CSPM_OPT_SWEEP_FOLD: they leave the other pairs' kernels their registers)")
     ap.add_argument("--schedule", default="raster", choices=["raster", "redblack"])
     ap.add_argument("--rb-rounds", type=int, default=1)
@@ -207,8 +209,10 @@ def main():
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU: libcspm_hip has no CPU fallback")
     backend = os.environ.get("CSPM_BENCH_BACKEND", "nccl")  # "gloo": only to exercise the N>1 control flow on a 1-GPU box
-    if args.gpus < 1 or args.in_flight < 1:
-        raise SystemExit("--gpus and --in-flight must be >= 1")
+    if args.gpus < 1 or args.in_flight < 0:
+        raise SystemExit("--gpus must be >= 1 and --in-flight >= 0")
+    if args.in_flight == 0:
+        args.in_flight = 2 if synth.CONFIGS[args.config]["w"] * synth.CONFIGS[args.config]["h"] >= 400000 else 4
     if backend == "nccl" and ndev < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes only {ndev} GPU(s); one rank per GPU is required "
                          f"(set CSPM_BENCH_BACKEND=gloo to exercise the N>1 control flow with ranks sharing a GPU)")
