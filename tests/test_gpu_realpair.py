@@ -234,3 +234,33 @@ def test_real_half_size_pair_accuracy_next_to_the_reference_probe(gpu_ctx):
     _record("half_370x250_D32_GRD_cs", {"gpu_raw_bad2": bad, "gpu_post_processed_bad2": rd.bad_fraction(lo.astype(np.float64) / cfg["dis_scale"], gt, 2.0),
                                         "reference_probe_raw_bad2": "0.109-0.111 (SURVEY.md 8(c), unmodified reference, clock-seeded)"})
     assert 0.07 < bad < 0.15, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["redblack", "row_shared_rng", "volumes", "computed_tables", "per_diagonal", "folded_sweep", "lambda0", "lambda1", "source_order_view"])
+def test_real_crop_every_mode_bit_exact(gpu_ctx, mode):
+    """the photograph through the modes the synthetic pairs are tested in: the red-black schedule, the reference's USE_OMP random
+    streams (one per row), materialised f64 volumes, computed instead of DMA-filled tables, per-diagonal sweep launches, the folded
+    sweep, the reference CLI's default lambda = 0 and lambda = 1, view propagation in source order -- GRD cross-scale, 2 iterations
+    + post-processing, every plane and map identical to the oracle run the same way"""
+    from crossscalepatchmatch_amd import capi
+    cfg, l, r, _ = rd.load_crop()
+    lam = {"lambda0": 0.0, "lambda1": 1.0}.get(mode, 0.3)
+    sched = po.SCHED_REDBLACK if mode == "redblack" else po.SCHED_RASTER
+    rng_mode = po.RNG_ROW_SHARED if mode == "row_shared_rng" else po.RNG_PER_PIXEL
+    try:
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, int(mode == "per_diagonal"))
+        gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, int(mode == "folded_sweep"))
+        gpu_ctx.set_option(capi.OPT_VIEW_SORT, int(mode != "source_order_view"))
+        gpu_ctx.set_images(l, r)
+        gpu_ctx.build_cost_grd(cfg["max_dis"], 35, 5, lam, volumes=(mode == "volumes"), table_volumes=(mode != "computed_tables"))
+        gpu_ctx.patchmatch(2, seed=77, schedule=sched, rng_mode=rng_mode, rb_rounds=2 if mode == "redblack" else 1)
+        pc = po.PlaneCost(l, r, cfg["max_dis"], 35, 5, lam)
+        pm = po.PatchMatch(l, r, cfg["max_dis"], cfg["dis_scale"])
+        pm.run(2, pc, False, seed=77, schedule=sched, sum_order=po.SUM_DEVICE, rng_mode=rng_mode, rb_rounds=2 if mode == "redblack" else 1,
+               wavefront=(sched == po.SCHED_RASTER))
+        _assert_equals_oracle(gpu_ctx, pm, cfg, mode)
+    finally:
+        gpu_ctx.set_option(capi.OPT_RASTER_LAUNCHES, 0)
+        gpu_ctx.set_option(capi.OPT_SWEEP_FOLD, 0)
+        gpu_ctx.set_option(capi.OPT_VIEW_SORT, 1)
