@@ -506,7 +506,11 @@ def main():
         if nfl > 1:
             out["kernel_ms_one_pair_alone"] = {k: v["ms"] for k, v in solo.items()}
         if world == 1 and not args.no_cpu_baseline and args.cc == "GRD":
-            out["cpu_baseline"] = cpu_baseline(dev_index, crop=args.cpu_crop, extra_legs=not args.cpu_c3_only)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dev_index, crop=args.cpu_crop, extra_legs=not args.cpu_c3_only)
+            except Exception as e:  # the timed result must not be lost to a problem of the reporting leg: say so in its place
+                out["cpu_baseline"] = {"error": repr(e)}
+                print("bench.py: the cpu_baseline leg failed: %r" % (e,), file=sys.stderr)
         # sanity of the LAST pair that was timed (not part of the timed region)
         if batch_mode:  # rank 0's last own pair: index steps-1 of the batch; its 8-bit map came back through the gather
             gl = host_pairs[min(args.steps, npairs) - 1][3]
@@ -516,7 +520,11 @@ def main():
             out["bad2_vs_gt_left"] = synth.bad_fraction(last.disparity_f64(0), gl, 2.0)
         out["distinct_pairs"] = npairs
         if world == 1 and not args.no_real_pair:
-            out["real_pair_bad2"] = real_pair_accuracy(dev_index)
+            try:
+                out["real_pair_bad2"] = real_pair_accuracy(dev_index)
+            except Exception as e:
+                out["real_pair_bad2"] = {"error": repr(e)}
+                print("bench.py: the real-pair leg failed: %r" % (e,), file=sys.stderr)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
         if sweep_fallbacks or volume_fallbacks:
