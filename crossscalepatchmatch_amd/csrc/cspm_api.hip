@@ -905,12 +905,12 @@ int do_spatial(cspm_ctx *c, int iter, const cspm_pm_params *p) {
       HIPCHK(c, hipMemsetAsync(c->d_sweep_qctl, 0, 4 * sizeof(unsigned int), c->stream));
     }
     int ncu = c->ncu;
-    // Workgroups per CU when the caller has not chosen (CSPM_OPT_SWEEP_WG = 0): 2 -- a KITTI-size sweep is bound by its dependency chain and
-    // gets no faster with more (20.1 / 19.6 ms with 2 / 3), while every resident workgroup holds registers other pairs' kernels want.  A sweep
-    // whose anti-diagonals are many times wider than the resident workgroups is bound by THROUGHPUT instead: 3000 x 2000 (4000 pixels per
-    // middle diagonal against 512 workgroups) takes 278.8 ms with 2 per CU and 214.4 with 3 (the most five-wave workgroups of 88 VGPRs a CU
-    // holds; profiles/r06_c5/).  Not for folded sweeps: their caller shares the GPU, and with three pairs in flight 2 per CU measured best.
-    const bool wide = 2LL * std::min(c->W, c->H) >= 8LL * c->ncu && !sweep_folded(c);
+    // Workgroups per CU when the caller has not chosen (CSPM_OPT_SWEEP_WG = 0): 2 for a KITTI-size sweep -- bound by its dependency chain,
+    // 19.3 / 18.5 ms with 2 / 3, while every resident workgroup holds registers other pairs' kernels want -- and 3 (the most five-wave
+    // workgroups of 88 VGPRs a CU holds) once the anti-diagonals are wide enough for THROUGHPUT to bind: 1242 x 600 31.1 -> 27.1 ms,
+    // 1600 x 1000 72.0 -> 58.5, 3000 x 2000 274.7 -> 214.8 (tools/exp_wg_threshold.py, profiles/r06_c5/).  Not for folded sweeps: their
+    // caller shares the GPU, and with pairs in flight 2 per CU measured best.
+    const bool wide = 2LL * std::min(c->W, c->H) >= 4LL * c->ncu && !sweep_folded(c);
     const int wg_per_cu = c->sweep_wg_per_cu > 0 ? c->sweep_wg_per_cu : (wide ? 3 : 2);
     // more workgroups than fit is harmless (unclaimed work is all a late workgroup needs); at least one per band, a multiple of
     // the bands so that every band gets the same number

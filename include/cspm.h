@@ -137,7 +137,7 @@ int cspm_build_cost_grd(cspm_ctx *ctx, int max_dis, int wnd_size, int scale_num,
 /* CSPM_OPT_SWEEP_WG (default 0 = the library chooses): workgroups of the persistent raster sweep launched per CU.  The library's choice is 2 --
  * a KITTI-size sweep is bound by its dependency chain (one: 29 instead of 20 ms per sweep; three: no faster) and every resident workgroup
  * holds registers another pair's kernels would use -- and 3 for images whose anti-diagonals are many times wider than the resident
- * workgroups (2 * min(w, h) >= 8 * CUs, e.g. 3000 x 2000: 214 instead of 279 ms per sweep) unless CSPM_OPT_SWEEP_FOLD says that the GPU is
+ * workgroups (2 * min(w, h) >= 4 * CUs: 1242 x 600 27 instead of 31 ms per sweep, 3000 x 2000 215 instead of 275) unless CSPM_OPT_SWEEP_FOLD says that the GPU is
  * shared.  Any value gives identical planes. */
 #define CSPM_OPT_SWEEP_WG 14
 /* CSPM_OPT_VOLUME_RETRY_PAIRS (default 16; 0 = never): a cost object that wanted optional volumes and runs without them (free-memory veto
